@@ -1,0 +1,122 @@
+/* rt_hip.h — C ABI of librt_hip.so: the MI355X (gfx950) replacement for the reference's
+ * path-tracing compute pass.
+ *
+ * The reference has no FFI for this path; its seam is the Rust struct `Raytracer`
+ * (reference src/raytracing.rs:6-13). Each entry point below names the piece of that seam it
+ * replaces. A Rust host binds these with `extern "C"` (INTEGRATION.md shows the ffi.rs stub).
+ *
+ * Conventions: opaque handle, POD in/out, plain pointers and sizes, int status (0 = ok, <0 = error,
+ * message via rt_last_error()). Nothing throws or aborts. One context drives one GPU from one
+ * host thread at a time (the reference is single-threaded: src/lib.rs:29). All work is queued on
+ * the context's HIP stream; rt_sync() is the equivalent of queue.submit + wait.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+#define RT_OK 0
+#define RT_ERR_INVALID -1   /* bad argument */
+#define RT_ERR_HIP -2       /* a HIP runtime call failed */
+#define RT_ERR_STATE -3     /* call order: scene/camera not set */
+#define RT_ERR_NO_DEVICE -4 /* no usable gfx950 device: the library never falls back to the CPU */
+
+/* Raytracer::new (raytracing.rs:16-156): allocates the W x H accumulation image (zero-initialised,
+ * as wgpu zero-initialises color_buffer/color_cache, raytracing.rs:20-52) on HIP device `device`.
+ * `flags` = RT_ACCUM_* | RT_DISPATCH_* | RT_SHADE_* | RT_MATH_* | RT_COMBINE_* (rt_types.h). */
+int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_t flags);
+
+/* drop(Raytracer) */
+void rt_destroy(rt_ctx* ctx);
+
+/* World::new buffer uploads (world.rs:46-56): `n_spheres` x 32 B and `n_materials` x 32 B host
+ * images in the reference's Pod layouts. Copied; the caller keeps ownership. Every
+ * material_index must be < n_materials (the reference's random_bunch can emit out-of-range
+ * indices, objects.rs:37, whose effect is driver-defined; here it is RT_ERR_INVALID). */
+int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, const rt_material* materials,
+                 uint32_t n_materials);
+
+/* queue.write_buffer(camera) (camera.rs:264,285-287): the 160-byte CameraRaw, carrying
+ * samples_per_pixel, frames_to_render and current_frame. */
+int rt_set_camera(rt_ctx* ctx, const rt_camera_raw* camera);
+
+/* Time::add_delta's write of the time uniform (time.rs:75), passed as the f32's bit pattern:
+ * the kernel only ever uses the bits (raytrace_kernal.wgsl:260). */
+int rt_set_time(rt_ctx* ctx, uint32_t time_bits);
+
+/* Raytracer::compute (raytracing.rs:178-200): one compute pass with the current camera and time —
+ * trace samples_per_pixel paths per covered pixel, fold into the accumulation image; the
+ * color_buffer -> color_cache copy is implicit (one in-place image). Asynchronous. Does nothing
+ * when camera.current_frame >= camera.frames_to_render (raytrace_kernal.wgsl:76). */
+int rt_compute(rt_ctx* ctx);
+
+/* Batched form of the App::update/App::render loop (app.rs:93-116) for `n_frames` redraws in ONE
+ * launch: frame k uses time_bits[k] and current_frame = camera.current_frame + k; frames at or past
+ * frames_to_render are skipped as the reference skips them. On return the context's camera has
+ * current_frame advanced by n_frames and its time is time_bits[n_frames-1]. Results are
+ * bit-identical to n_frames x (rt_set_time, rt_compute, current_frame += 1). Asynchronous. */
+int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames);
+
+/* queue.submit + device wait (app.rs:111). */
+int rt_sync(rt_ctx* ctx);
+
+/* What Screen::render would sample (color_cache, screen.rs:91-93): W*H*4 bytes RGBA8. In
+ * RT_ACCUM_F32 mode the float image is quantised on the fly with the rgba8unorm rule. Synchronous. */
+int rt_read_rgba8(rt_ctx* ctx, void* dst, size_t bytes);
+
+/* The float4 accumulation image, W*H*16 bytes (RT_ACCUM_F32 contexts only). Synchronous. */
+int rt_read_accum_f32(rt_ctx* ctx, void* dst, size_t bytes);
+
+/* Test hook: final RNG state (u32) of every pixel after the most recent pass, W*H*4 bytes; pixels
+ * no pass covered read 0. Recording is off until rt_enable_rng_capture(ctx, 1). Synchronous. */
+int rt_enable_rng_capture(rt_ctx* ctx, int enable);
+int rt_read_rng_state(rt_ctx* ctx, void* dst, size_t bytes);
+
+/* Event counters (rays, sphere tests, ... rt_counters in rt_types.h) accumulated by passes run
+ * while counting is enabled; they feed rays/s and the algorithmic-FLOP roofline figure. Counting
+ * launches an instrumented kernel variant, so leave it off in timed runs. */
+int rt_enable_counters(rt_ctx* ctx, int enable);
+int rt_get_counters(rt_ctx* ctx, rt_counters* out); /* synchronous */
+int rt_reset_counters(rt_ctx* ctx);
+
+/* Multi-GPU tile split (no counterpart in the reference, which drives one device): this context
+ * renders only the 8x8 pixel tiles t, numbered row-major over the covered area, with
+ * t % world == rank. Pixels of other ranks' tiles stay zero, so the per-GPU images combine with a
+ * plain sum (RCCL reduce). Default rank 0 of 1. */
+int rt_set_partition(rt_ctx* ctx, uint32_t rank, uint32_t world);
+
+/* Plumbing for callers that own device memory / streams (torch.distributed, HIP graphs):
+ * rt_accum_device_ptr: device address and byte size of the accumulation image (RGBA8: W*H*4,
+ *   F32: W*H*16), valid until rt_destroy.
+ * rt_set_stream: run on the caller's hipStream_t (NULL = the context's own stream). */
+int rt_accum_device_ptr(rt_ctx* ctx, void** dptr, size_t* bytes);
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
+/* zero the accumulation image and RNG capture (a fresh Raytracer::new without reallocating) */
+int rt_clear(rt_ctx* ctx);
+
+/* Timing hook: average device time in milliseconds of the trace kernel over the launches made
+ * since the last rt_timing_reset, measured with hipEvents recorded on the launch stream around
+ * every launch while timing is enabled. Synchronous. */
+int rt_enable_timing(rt_ctx* ctx, int enable);
+int rt_timing_reset(rt_ctx* ctx);
+int rt_timing_get(rt_ctx* ctx, double* total_ms, uint32_t* launches);
+
+/* Device facts for reports: name, compute units, clock (kHz). */
+int rt_device_info(rt_ctx* ctx, char* name, size_t name_bytes, int* compute_units, int* clock_khz);
+
+/* Thread-local message for the last non-zero status returned on this thread. */
+const char* rt_last_error(void);
+
+/* Library version string. */
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,447 @@
+// rt_api.cpp — the C ABI of librt_hip.so (include/rt_hip.h): context, scene re-layout, launches.
+// Replaces the wgpu half of the reference's Raytracer (src/raytracing.rs:15-201). There is no CPU
+// fallback anywhere in this library: without a gfx950 device rt_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_hip.h"
+#include "rt_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define RT_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess)                                                                        \
+      return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                \
+  } while (0)
+
+}  // namespace
+
+struct rt_ctx {
+  int device = 0;
+  uint32_t width = 0, height = 0, flags = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  void* accum = nullptr;
+  size_t accum_bytes = 0;
+  uint32_t* rng = nullptr;  // allocated on first rt_enable_rng_capture
+  bool rng_capture = false;
+  unsigned long long* counters = nullptr;
+  bool counting = false;
+  rt_f32x4 *sph_test = nullptr, *sph_shade = nullptr, *sph_col = nullptr;
+  uint32_t n_spheres = 0;
+  bool have_scene = false, have_camera = false, have_time = false;
+  rt_camera_raw camera{};
+  uint32_t time_bits = 0;
+  uint32_t rank = 0, world = 1;
+  // time table for batched launches: pinned staging + device copy, guarded by an event
+  uint32_t* time_host = nullptr;
+  uint32_t* time_dev = nullptr;
+  size_t time_cap = 0;
+  hipEvent_t time_copied = nullptr;
+  bool time_pending = false;
+  // RGBA8 view of a float image
+  void* quant = nullptr;
+  // per-launch timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+};
+
+namespace {
+
+int check(rt_ctx* ctx) {
+  if (!ctx) return fail(RT_ERR_INVALID, "null context");
+  RT_HIP(hipSetDevice(ctx->device));
+  return RT_OK;
+}
+
+void covered(const rt_ctx* c, uint32_t* cov_w, uint32_t* cov_h) {
+  // raytracing.rs:192: dispatch_workgroups(width/16, height/16, 1) of 16x16 invocations
+  if (c->flags & RT_DISPATCH_FULL) {
+    *cov_w = c->width;
+    *cov_h = c->height;
+  } else {
+    *cov_w = (c->width / RT_WORKGROUP) * RT_WORKGROUP;
+    *cov_h = (c->height / RT_WORKGROUP) * RT_WORKGROUP;
+  }
+}
+
+int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_bits0, const uint32_t* time_table_dev) {
+  rt_kargs a{};
+  std::memcpy(a.p2w, ctx->camera.pixel_to_world, sizeof a.p2w);
+  a.pos[0] = ctx->camera.pos[0];
+  a.pos[1] = ctx->camera.pos[1];
+  a.pos[2] = ctx->camera.pos[2];
+  a.width = ctx->width;
+  a.height = ctx->height;
+  covered(ctx, &a.cov_w, &a.cov_h);
+  a.tiles_x = (a.cov_w + 7u) / 8u;
+  a.n_tiles = a.tiles_x * ((a.cov_h + 7u) / 8u);
+  a.rank = ctx->rank;
+  a.world = ctx->world;
+  a.spp = ctx->camera.samples_per_pixel;
+  a.first_frame = first_frame;
+  a.n_frames = n_frames;
+  a.time_bits0 = time_bits0;
+  a.time_table = time_table_dev;
+  a.n_spheres = ctx->n_spheres;
+  a.flags = ctx->flags;
+  a.sph_test = ctx->sph_test;
+  a.sph_shade = ctx->sph_shade;
+  a.sph_col = ctx->sph_col;
+  a.accum = ctx->accum;
+  a.rng_out = ctx->rng_capture ? ctx->rng : nullptr;
+  a.counters = ctx->counters;
+  if (a.n_tiles == 0) return RT_OK;
+  const uint32_t my_tiles = a.n_tiles > a.rank ? (a.n_tiles - a.rank + a.world - 1u) / a.world : 0u;
+  // host-side shape check before the launch: every tile index a block can form is < n_tiles or
+  // rejected by the kernel's own guard; every pixel index is < width*height by construction of cov_*
+  if (a.cov_w > a.width || a.cov_h > a.height) return fail(RT_ERR_INVALID, "covered area exceeds the image");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->timing) {
+    if (ctx->events_used == ctx->events.size()) {
+      RT_HIP(hipEventCreate(&e0));
+      RT_HIP(hipEventCreate(&e1));
+      ctx->events.emplace_back(e0, e1);
+    }
+    e0 = ctx->events[ctx->events_used].first;
+    e1 = ctx->events[ctx->events_used].second;
+    ctx->events_used++;
+    RT_HIP(hipEventRecord(e0, ctx->stream));
+  }
+  const bool strict = (ctx->flags & RT_MATH_FAST) == 0;
+  RT_HIP(rt_launch_path_kernel(a, my_tiles, strict, ctx->counting, ctx->stream));
+  if (ctx->timing) RT_HIP(hipEventRecord(e1, ctx->stream));
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+const char* rt_version(void) { return "raytracer_amd 0.1 (gfx950)"; }
+
+int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_t flags) {
+  if (!out) return fail(RT_ERR_INVALID, "out is null");
+  *out = nullptr;
+  if (width == 0 || height == 0 || width > 65536u || height > 65536u) return fail(RT_ERR_INVALID, "bad image size");
+  const uint32_t known = RT_ACCUM_F32 | RT_DISPATCH_FULL | RT_SHADE_CHECKER | RT_MATH_FAST | RT_COMBINE_SUM;
+  if (flags & ~known) return fail(RT_ERR_INVALID, "unknown flag bits");
+  if ((flags & RT_COMBINE_SUM) && !(flags & RT_ACCUM_F32))
+    return fail(RT_ERR_INVALID, "RT_COMBINE_SUM needs RT_ACCUM_F32 (the quantised recurrence is order dependent)");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(RT_ERR_NO_DEVICE, "no HIP device visible; librt_hip has no CPU path");
+  if (device < 0 || device >= n_dev) return fail(RT_ERR_INVALID, "device index out of range");
+  hipDeviceProp_t prop;
+  RT_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(RT_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  RT_HIP(hipSetDevice(device));
+  rt_ctx* c = new (std::nothrow) rt_ctx();
+  if (!c) return fail(RT_ERR_INVALID, "out of host memory");
+  c->device = device;
+  c->width = width;
+  c->height = height;
+  c->flags = flags;
+  const size_t px = (size_t)width * height;
+  c->accum_bytes = px * ((flags & RT_ACCUM_F32) ? 16u : 4u);
+  hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&c->accum, c->accum_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 12 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
+  if (e == hipSuccess) {
+    c->stream = c->own_stream;
+    e = hipMemsetAsync(c->accum, 0, c->accum_bytes, c->stream);
+  }
+  if (e == hipSuccess) e = hipMemsetAsync(c->counters, 0, 12 * sizeof(unsigned long long), c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    const std::string msg = std::string("rt_create: ") + hipGetErrorString(e);
+    rt_destroy(c);
+    return fail(RT_ERR_HIP, msg);
+  }
+  *out = c;
+  return RT_OK;
+}
+
+void rt_destroy(rt_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& ev : c->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (c->time_copied) (void)hipEventDestroy(c->time_copied);
+  (void)hipFree(c->accum);
+  (void)hipFree(c->rng);
+  (void)hipFree(c->counters);
+  (void)hipFree(c->sph_test);
+  (void)hipFree(c->sph_shade);
+  (void)hipFree(c->sph_col);
+  (void)hipFree(c->time_dev);
+  (void)hipFree(c->quant);
+  if (c->time_host) (void)hipHostFree(c->time_host);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, const rt_material* materials,
+                 uint32_t n_materials) {
+  if (int rc = check(ctx)) return rc;
+  if (!spheres || !materials || n_spheres == 0 || n_materials == 0) return fail(RT_ERR_INVALID, "empty scene");
+  if (n_spheres > (1u << 24)) return fail(RT_ERR_INVALID, "too many spheres");
+  std::vector<rt_f32x4> test(n_spheres), shade(n_spheres), col(n_spheres);
+  for (uint32_t i = 0; i < n_spheres; ++i) {
+    const rt_sphere& s = spheres[i];
+    if (s.material_index >= n_materials)
+      return fail(RT_ERR_INVALID, "sphere " + std::to_string(i) + ": material_index out of range");
+    const rt_material& m = materials[s.material_index];
+    // fl(r*r) is the same single rounding the shader performs per test (wgsl:210); hoisting it is bit-safe
+    const volatile float r = s.radius;
+    const float rr = r * r;
+    const float inv_r = 1.0f / r;
+    test[i] = rt_f32x4{s.center[0], s.center[1], s.center[2], rr};
+    shade[i] = rt_f32x4{s.center[0], s.center[1], s.center[2], s.radius};
+    col[i] = rt_f32x4{m.color[0], m.color[1], m.color[2], inv_r};
+  }
+  RT_HIP(hipStreamSynchronize(ctx->stream));  // no launch may still read the old arrays
+  (void)hipFree(ctx->sph_test);
+  (void)hipFree(ctx->sph_shade);
+  (void)hipFree(ctx->sph_col);
+  ctx->sph_test = ctx->sph_shade = ctx->sph_col = nullptr;
+  ctx->have_scene = false;
+  const size_t bytes = (size_t)n_spheres * sizeof(rt_f32x4);
+  RT_HIP(hipMalloc((void**)&ctx->sph_test, bytes));
+  RT_HIP(hipMalloc((void**)&ctx->sph_shade, bytes));
+  RT_HIP(hipMalloc((void**)&ctx->sph_col, bytes));
+  RT_HIP(hipMemcpy(ctx->sph_test, test.data(), bytes, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(ctx->sph_shade, shade.data(), bytes, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(ctx->sph_col, col.data(), bytes, hipMemcpyHostToDevice));
+  ctx->n_spheres = n_spheres;
+  ctx->have_scene = true;
+  return RT_OK;
+}
+
+int rt_set_camera(rt_ctx* ctx, const rt_camera_raw* camera) {
+  if (int rc = check(ctx)) return rc;
+  if (!camera) return fail(RT_ERR_INVALID, "camera is null");
+  if (camera->samples_per_pixel == 0)
+    return fail(RT_ERR_INVALID, "samples_per_pixel must be >= 1 (the reference clamps it to [1,256], camera.rs:136-137)");
+  ctx->camera = *camera;
+  ctx->have_camera = true;
+  return RT_OK;
+}
+
+int rt_set_time(rt_ctx* ctx, uint32_t time_bits) {
+  if (int rc = check(ctx)) return rc;
+  ctx->time_bits = time_bits;
+  ctx->have_time = true;
+  return RT_OK;
+}
+
+int rt_compute(rt_ctx* ctx) {
+  if (int rc = check(ctx)) return rc;
+  if (!ctx->have_scene || !ctx->have_camera || !ctx->have_time)
+    return fail(RT_ERR_STATE, "rt_compute before rt_set_scene / rt_set_camera / rt_set_time");
+  if (ctx->camera.current_frame >= ctx->camera.frames_to_render) return RT_OK;  // wgsl:76
+  return launch(ctx, ctx->camera.current_frame, 1, ctx->time_bits, nullptr);
+}
+
+int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames) {
+  if (int rc = check(ctx)) return rc;
+  if (!ctx->have_scene || !ctx->have_camera) return fail(RT_ERR_STATE, "rt_render_frames before rt_set_scene / rt_set_camera");
+  if (!time_bits || n_frames == 0) return fail(RT_ERR_INVALID, "empty time table");
+  const uint32_t cur = ctx->camera.current_frame, total = ctx->camera.frames_to_render;
+  const uint32_t live = cur < total ? (n_frames < total - cur ? n_frames : total - cur) : 0u;  // rest are no-ops (wgsl:76)
+  int rc = RT_OK;
+  if (live == 1) {
+    rc = launch(ctx, cur, 1, time_bits[0], nullptr);
+  } else if (live > 1) {
+    if (ctx->time_pending) {  // the staging buffer may still be in flight from the previous batch
+      RT_HIP(hipEventSynchronize(ctx->time_copied));
+      ctx->time_pending = false;
+    }
+    if (live > ctx->time_cap) {
+      RT_HIP(hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->time_dev);
+      if (ctx->time_host) (void)hipHostFree(ctx->time_host);
+      ctx->time_dev = nullptr;
+      ctx->time_host = nullptr;
+      ctx->time_cap = 0;
+      size_t cap = 256;
+      while (cap < live) cap *= 2;
+      RT_HIP(hipMalloc((void**)&ctx->time_dev, cap * sizeof(uint32_t)));
+      RT_HIP(hipHostMalloc((void**)&ctx->time_host, cap * sizeof(uint32_t), hipHostMallocDefault));
+      ctx->time_cap = cap;
+    }
+    std::memcpy(ctx->time_host, time_bits, live * sizeof(uint32_t));
+    RT_HIP(hipMemcpyAsync(ctx->time_dev, ctx->time_host, live * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(hipEventRecord(ctx->time_copied, ctx->stream));
+    ctx->time_pending = true;
+    rc = launch(ctx, cur, live, time_bits[0], ctx->time_dev);
+  }
+  if (rc != RT_OK) return rc;
+  ctx->camera.current_frame = cur + n_frames;  // Camera::increase_frame once per redraw (camera.rs:253)
+  ctx->time_bits = time_bits[n_frames - 1];
+  ctx->have_time = true;
+  return RT_OK;
+}
+
+int rt_sync(rt_ctx* ctx) {
+  if (int rc = check(ctx)) return rc;
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_read_rgba8(rt_ctx* ctx, void* dst, size_t bytes) {
+  if (int rc = check(ctx)) return rc;
+  const size_t px = (size_t)ctx->width * ctx->height;
+  if (!dst || bytes != px * 4u) return fail(RT_ERR_INVALID, "rt_read_rgba8: need width*height*4 bytes");
+  const void* src = ctx->accum;
+  if (ctx->flags & RT_ACCUM_F32) {
+    if (!ctx->quant) RT_HIP(hipMalloc(&ctx->quant, px * 4u));
+    RT_HIP(rt_launch_quantize(ctx->accum, ctx->quant, px, ctx->stream));
+    src = ctx->quant;
+  }
+  RT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_read_accum_f32(rt_ctx* ctx, void* dst, size_t bytes) {
+  if (int rc = check(ctx)) return rc;
+  if (!(ctx->flags & RT_ACCUM_F32)) return fail(RT_ERR_STATE, "rt_read_accum_f32 on an RT_ACCUM_RGBA8 context");
+  if (!dst || bytes != ctx->accum_bytes) return fail(RT_ERR_INVALID, "rt_read_accum_f32: need width*height*16 bytes");
+  RT_HIP(hipMemcpyAsync(dst, ctx->accum, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_enable_rng_capture(rt_ctx* ctx, int enable) {
+  if (int rc = check(ctx)) return rc;
+  if (enable && !ctx->rng) {
+    const size_t bytes = (size_t)ctx->width * ctx->height * sizeof(uint32_t);
+    RT_HIP(hipMalloc((void**)&ctx->rng, bytes));
+    RT_HIP(hipMemsetAsync(ctx->rng, 0, bytes, ctx->stream));
+  }
+  ctx->rng_capture = enable != 0;
+  return RT_OK;
+}
+
+int rt_read_rng_state(rt_ctx* ctx, void* dst, size_t bytes) {
+  if (int rc = check(ctx)) return rc;
+  if (!ctx->rng) return fail(RT_ERR_STATE, "rt_read_rng_state before rt_enable_rng_capture");
+  if (!dst || bytes != (size_t)ctx->width * ctx->height * 4u) return fail(RT_ERR_INVALID, "rt_read_rng_state: need width*height*4 bytes");
+  RT_HIP(hipMemcpyAsync(dst, ctx->rng, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_enable_counters(rt_ctx* ctx, int enable) {
+  if (int rc = check(ctx)) return rc;
+  ctx->counting = enable != 0;
+  return RT_OK;
+}
+
+int rt_get_counters(rt_ctx* ctx, rt_counters* out) {
+  if (int rc = check(ctx)) return rc;
+  if (!out) return fail(RT_ERR_INVALID, "out is null");
+  unsigned long long h[12];
+  RT_HIP(hipMemcpyAsync(h, ctx->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  out->T = h[0]; out->D = h[1]; out->H = h[2]; out->R = h[3]; out->M = h[4]; out->S = h[5];
+  out->Sm = h[6]; out->J = h[7]; out->Sd = h[8]; out->N = h[9]; out->P = h[10]; out->rand_calls = h[11];
+  return RT_OK;
+}
+
+int rt_reset_counters(rt_ctx* ctx) {
+  if (int rc = check(ctx)) return rc;
+  RT_HIP(hipMemsetAsync(ctx->counters, 0, 12 * sizeof(unsigned long long), ctx->stream));
+  return RT_OK;
+}
+
+int rt_set_partition(rt_ctx* ctx, uint32_t rank, uint32_t world) {
+  if (int rc = check(ctx)) return rc;
+  if (world == 0 || rank >= world) return fail(RT_ERR_INVALID, "need rank < world");
+  ctx->rank = rank;
+  ctx->world = world;
+  return RT_OK;
+}
+
+int rt_accum_device_ptr(rt_ctx* ctx, void** dptr, size_t* bytes) {
+  if (int rc = check(ctx)) return rc;
+  if (!dptr || !bytes) return fail(RT_ERR_INVALID, "null out pointer");
+  *dptr = ctx->accum;
+  *bytes = ctx->accum_bytes;
+  return RT_OK;
+}
+
+int rt_set_stream(rt_ctx* ctx, void* hip_stream) {
+  if (int rc = check(ctx)) return rc;
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return RT_OK;
+}
+
+int rt_clear(rt_ctx* ctx) {
+  if (int rc = check(ctx)) return rc;
+  RT_HIP(hipMemsetAsync(ctx->accum, 0, ctx->accum_bytes, ctx->stream));
+  if (ctx->rng) RT_HIP(hipMemsetAsync(ctx->rng, 0, (size_t)ctx->width * ctx->height * 4u, ctx->stream));
+  return RT_OK;
+}
+
+int rt_enable_timing(rt_ctx* ctx, int enable) {
+  if (int rc = check(ctx)) return rc;
+  ctx->timing = enable != 0;
+  return RT_OK;
+}
+
+int rt_timing_reset(rt_ctx* ctx) {
+  if (int rc = check(ctx)) return rc;
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->events_used = 0;
+  return RT_OK;
+}
+
+int rt_timing_get(rt_ctx* ctx, double* total_ms, uint32_t* launches) {
+  if (int rc = check(ctx)) return rc;
+  if (!total_ms || !launches) return fail(RT_ERR_INVALID, "null out pointer");
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  double sum = 0.0;
+  for (size_t i = 0; i < ctx->events_used; ++i) {
+    float ms = 0.f;
+    RT_HIP(hipEventElapsedTime(&ms, ctx->events[i].first, ctx->events[i].second));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = (uint32_t)ctx->events_used;
+  return RT_OK;
+}
+
+int rt_device_info(rt_ctx* ctx, char* name, size_t name_bytes, int* compute_units, int* clock_khz) {
+  if (int rc = check(ctx)) return rc;
+  hipDeviceProp_t prop;
+  RT_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  if (name && name_bytes) std::snprintf(name, name_bytes, "%s (%s)", prop.name, prop.gcnArchName);
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// rt_kernels.h — launch interface between the C ABI (rt_api.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_types.h"
+
+typedef float rt_f32x4 __attribute__((ext_vector_type(4)));
+
+// Kernel arguments (by value, lands in SGPRs). Scene arrays are the device-side re-layout built
+// by rt_set_scene: sph_test[i] = {cx, cy, cz, fl(r*r)} (hit loop, scalar loads),
+// sph_shade[i] = {cx, cy, cz, r}, sph_col[i] = {material.color.rgb, fl(1/r)} (per-hit fetch).
+struct rt_kargs {
+  float p2w[16];  // CameraRaw.pixel_to_world, column-major
+  float pos[3];   // CameraRaw.pos.xyz
+  uint32_t width, height;   // textureDimensions(color_buffer)
+  uint32_t cov_w, cov_h;    // pixels a pass covers (floor16 or full)
+  uint32_t tiles_x, n_tiles;  // 8x8 tiles over the covered area
+  uint32_t rank, world;     // tile t belongs to this launch iff t % world == rank
+  uint32_t spp;
+  uint32_t first_frame, n_frames;
+  uint32_t time_bits0;           // time bits of the first frame
+  const uint32_t* time_table;    // n_frames entries when n_frames > 1 (device), else may be null
+  uint32_t n_spheres;
+  uint32_t flags;
+  const rt_f32x4* sph_test;
+  const rt_f32x4* sph_shade;
+  const rt_f32x4* sph_col;
+  void* accum;                   // RGBA8: uint32 per pixel; F32: float4 per pixel
+  uint32_t* rng_out;             // optional
+  unsigned long long* counters;  // 12 x u64, COUNT variants only
+};
+
+hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t my_tiles, bool strict, bool count, hipStream_t stream);
+hipError_t rt_launch_quantize(const void* src_f32x4, void* dst_rgba8, size_t n_pixels, hipStream_t stream);

@@ -1,0 +1,45 @@
+"""Scratch perf probe (not the contract bench): times one compute pass per config/mode."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+import raytracer_amd as R
+import oracle_lib as O, scenes
+
+def flops(c):
+    return O.algorithmic_flops(c)
+
+def run(name, W, H, spp, scene, shade, math, reps=3, accum=R.RT_ACCUM_F32):
+    sp, mt = scene
+    flags = accum | shade | math
+    rt = R.Raytracer(W, H, flags)
+    rt.set_scene(sp, mt)
+    cam = scenes.camera_raw(W, H, spp=spp, frames=1000)
+    tb = O.time_bits_table(reps + 2)
+    # counters pass
+    rt.enable_counters(True)
+    rt.set_camera(cam); rt.set_time(int(tb[0])); rt.compute(); rt.sync()
+    c = rt.counters(); rt.enable_counters(False)
+    fl = flops(c)
+    rt.enable_timing(True)
+    for i in range(reps):
+        cam["current_frame"] = i + 1
+        rt.set_camera(cam); rt.set_time(int(tb[i + 1])); rt.compute()
+    ms, n = rt.timing()
+    ms /= n
+    samples = c["N"]
+    print(f"{name:28s} {'fast' if math else 'strict':6s} {ms:9.3f} ms  {samples/ms/1e6:8.2f} Gsamples/s  {c['R']/ms/1e6:8.2f} Grays/s  "
+          f"{fl/ms/1e9:7.2f} TFLOP/s ({fl/ms/1e9/157.3*100:5.1f}% of 157.3)  rays/sample {c['R']/samples:.2f} tests/ray {c['T']/c['R']:.0f}", flush=True)
+    rt.close()
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c3", "c3d", "c4"]
+    for math in (R.RT_MATH_STRICT, R.RT_MATH_FAST):
+        if "c2" in which:
+            run("C2 1080p 16spp default", 1920, 1080, 16, scenes.default_scene(1), 0, math)
+        if "c3d" in which:
+            run("4K 64spp default", 3840, 2160, 64, scenes.default_scene(1), 0, math)
+        if "c3" in which:
+            run("C3 4K 64spp checker20", 3840, 2160, 64, scenes.random_bunch(20, 3, 3), R.RT_SHADE_CHECKER, math)
+        if "c4" in which:
+            run("C4 1080p 4spp 1024sph", 1920, 1080, 4, scenes.random_bunch(1024, 16, 4), 0, math)
