@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py — the contract benchmark: samples/s of the path-tracing compute pass on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A STEP is one compute pass (`rt_compute`, reference Raytracer::compute, src/raytracing.rs:178-200)
+over the whole image of the workload BASELINE.json's metric is quoted on: C3 = 3840x2160, 64 spp,
+glowing-checkers scene (random_bunch(20)). With N GPUs the image is split by interleaved 8x8 tiles
+(strong scaling: the 4K frame is fixed); the per-GPU images are combined by ONE RCCL sum-reduce at
+the end of the render, inside the timed region.
+
+Prints ONE JSON line (rank 0). `value` = covered pixels x spp x K / seconds, whole job, inputs
+resident in HBM, RT_MATH_STRICT (the mode that is bit-identical to the oracle). Extra objects:
+  roofline     FP32 VALU roofline of the trace kernel: algorithmic FLOPs per launch (SURVEY.md §8d
+               formula over device event counters) / average launch duration (hipEvents on the
+               launch stream), against 157.3 TFLOP/s.
+  cpu_baseline the oracle (scalar C port, OpenMP) timed on this box's host cores on a bounded
+               tile sample of the same frame (rank 0, N = 1 only).
+  fast_math    the same measurement in RT_MATH_FAST (image within tolerance, not bit-exact).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_VALU_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz (packed FMA)
+
+
+def algorithmic_flops(c):
+    """17T + 4D + 12H + 6R + 15M + 8S + 12Sm + 11J + 7Sd + 8N + 110P."""
+    return (17 * c["T"] + 4 * c["D"] + 12 * c["H"] + 6 * c["R"] + 15 * c["M"] + 8 * c["S"] + 12 * c["Sm"]
+            + 11 * c["J"] + 7 * c["Sd"] + 8 * c["N"] + 110 * c["P"])
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=8)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--config", default="C3", help="C2 | C3 | C4 (C3 is the headline: 4K, 64 spp)")
+    p.add_argument("--math", default="strict", choices=["strict", "fast"])
+    p.add_argument("--split", default="tiles", choices=["tiles", "frames"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true", help="skip the fast_math side measurement")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    return p.parse_args()
+
+
+def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, device):
+    """Times `steps` compute passes. Returns dict(seconds, kernel_ms, launches, flops_per_launch, samples)."""
+    from raytracer_amd import dist as rdist
+    from raytracer_amd import host
+
+    W, H, spp = cfg["width"], cfg["height"], cfg["spp"]
+    frames_total = warmup + steps + 4
+    rt = R.Raytracer(W, H, flags, device=device)
+    rt.set_scene(cfg["spheres"], cfg["materials"])
+    img = rdist.DeviceImage(rt, f"cuda:{device}") if world > 1 else None
+    if split == "tiles":
+        rt.set_partition(rank, world)
+    tb = host.time_table(frames_total * (world if split == "frames" else 1))
+    cam = host.camera_raw(W, H, spp=spp, frames=frames_total * world)
+
+    def step(i):
+        # App::update + App::render for redraw i (reference app.rs:93-116)
+        f = i * world + rank if split == "frames" else i
+        rt.set_time(int(tb[f]))
+        cam["current_frame"] = f
+        rt.set_camera(cam)
+        rt.compute()
+
+    # algorithmic FLOPs per launch: instrumented variant on the first warmup-like frame (untimed)
+    rt.enable_counters(True)
+    step(0)
+    rt.sync()
+    counters = rt.counters()
+    rt.enable_counters(False)
+    rt.clear()
+    if img is not None:
+        img.zero_()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        step(i)
+    rt.sync()
+    rt.enable_timing(True)
+    rt.timing_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        step(i)
+    rt.sync()
+    if world > 1:
+        rdist.combine_sum(img.tensor, dst=0)  # ONE RCCL reduce per render
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    seconds = time.perf_counter() - t0
+    kernel_ms, launches = rt.timing()
+    info = rt.device_info()
+    rt.close()
+    cov_w = W if flags & R.RT_DISPATCH_FULL else (W // 16) * 16
+    cov_h = H if flags & R.RT_DISPATCH_FULL else (H // 16) * 16
+    samples_per_step = cov_w * cov_h * spp * (world if split == "frames" else 1)
+    return {"seconds": seconds, "kernel_ms": kernel_ms, "launches": launches, "counters": counters,
+            "flops_per_launch": algorithmic_flops(counters), "samples_per_step": samples_per_step, "device": info}
+
+
+def cpu_baseline(cfg, flags, target_seconds):
+    """The oracle on this box's host cores, on every `world`-th 8x8 tile of the same frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from raytracer_amd import host
+
+    W, H, spp = cfg["width"], cfg["height"], cfg["spp"]
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    oflags = flags & (O.ACCUM_F32 | O.DISPATCH_FULL | O.SHADE_CHECKER)
+    cam = host.camera_raw(W, H, spp=spp, frames=8)
+    tb = host.time_table(1)
+
+    def run(world):
+        img = O.OracleImage(W, H, oflags)
+        t0 = time.perf_counter()
+        O.compute(img, cfg["spheres"], cfg["materials"], cam, int(tb[0]), rank=0, world=world, threads=threads)
+        return time.perf_counter() - t0, img.counters_dict()
+
+    probe_world = 4096
+    dt, c = run(probe_world)
+    rate = c["N"] / max(dt, 1e-6)
+    total = (W // 16) * 16 * (H // 16) * 16 * spp
+    world = int(max(1, min(probe_world, round(total / max(rate * target_seconds, 1.0)))))
+    dt, c = run(world)
+    return {"value": c["N"] / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"one frame, every {world}-th 8x8 tile of the {W}x{H} image at {spp} spp "
+                      f"({c['N']} samples, {c['R']} rays, {dt:.1f} s), oracle/rt_oracle.c with OpenMP",
+            "rays_per_s": c["R"] / dt}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    import raytracer_amd as R
+    from raytracer_amd import configs
+
+    cfg = configs.get(args.config)
+    base_flags = cfg["flags"]
+    if args.split == "frames":
+        base_flags |= R.RT_ACCUM_F32 | R.RT_COMBINE_SUM
+    elif world > 1:
+        base_flags &= ~R.RT_COMBINE_SUM
+
+    def run(math):
+        flags = base_flags | (R.RT_MATH_FAST if math == "fast" else R.RT_MATH_STRICT)
+        m = measure(R, cfg, flags, rank, world, args.steps, args.warmup, args.split, dist, torch, local_rank)
+        sec = torch.tensor([m["seconds"]], dtype=torch.float64, device=f"cuda:{local_rank}")
+        if world > 1:
+            dist.all_reduce(sec, op=dist.ReduceOp.MAX)
+        m["seconds"] = float(sec.item())
+        return m
+
+    m = run(args.math)
+    extras = None
+    if not args.no_extras and world == 1:
+        extras = run("fast" if args.math == "strict" else "strict")
+
+    if rank == 0:
+        def roof(mm):
+            avg_ms = mm["kernel_ms"] / max(mm["launches"], 1)
+            achieved = mm["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
+            return {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "rt_path_kernel", "avg_launch_ms": round(avg_ms, 4),
+                    "algorithmic_flops_per_launch": mm["flops_per_launch"],
+                    "note": "FP32 vector roofline (no MFMA: no dense contraction); peak is the packed-FMA figure, "
+                            "78.6 TFLOP/s for non-packed FMA; FLOPs = SURVEY §8d formula over device event counters "
+                            "of one launch" + (" of rank 0's tiles" if world > 1 else "")}
+
+        total_samples = m["samples_per_step"] * args.steps
+        out = {
+            "metric": "samples/sec at 4K 64spp (path-tracing compute pass)" if args.config == "C3" else f"samples/sec ({args.config})",
+            "value": total_samples / m["seconds"],
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": m["seconds"] * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong" if args.split == "tiles" else "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{cfg['name']}: {cfg['description']}", "width": cfg["width"], "height": cfg["height"],
+                       "spp": cfg["spp"], "spheres": int(cfg["spheres"].shape[0]), "math": args.math,
+                       "accum": "f32" if base_flags & R.RT_ACCUM_F32 else "rgba8", "split": args.split,
+                       "step": "one rt_compute pass (one frame) over the whole image"},
+            "rays_per_s": m["counters"]["R"] * (world if args.split == "tiles" else 1) * args.steps / m["seconds"]
+            if world == 1 else None,
+            "roofline": roof(m),
+            "device": m["device"],
+        }
+        if extras is not None:
+            other = "fast" if args.math == "strict" else "strict"
+            out[f"{other}_math"] = {"value": extras["samples_per_step"] * args.steps / extras["seconds"], "unit": "samples/s",
+                                    "ms_per_step": extras["seconds"] * 1e3 / args.steps, "roofline": roof(extras),
+                                    "parity": "image within PSNR >= 40 dB of strict; RNG function bit-exact" if other == "fast"
+                                    else "bit-identical to the oracle"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, base_flags, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

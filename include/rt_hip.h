@@ -96,6 +96,11 @@ int rt_set_partition(rt_ctx* ctx, uint32_t rank, uint32_t world);
  *   F32: W*H*16), valid until rt_destroy.
  * rt_set_stream: run on the caller's hipStream_t (NULL = the context's own stream). */
 int rt_accum_device_ptr(rt_ctx* ctx, void** dptr, size_t* bytes);
+/* rt_bind_accum: use caller-owned device memory (e.g. a torch tensor handed to RCCL) as the
+ *   accumulation image from now on; `bytes` must equal the image size and the memory must stay
+ *   valid until rt_destroy or the next bind. The contents are used as they are (not cleared).
+ *   dptr = NULL returns to the context's own image. */
+int rt_bind_accum(rt_ctx* ctx, void* dptr, size_t bytes);
 int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 /* zero the accumulation image and RNG capture (a fresh Raytracer::new without reallocating) */
 int rt_clear(rt_ctx* ctx);

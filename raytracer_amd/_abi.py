@@ -55,6 +55,7 @@ SIGNATURES = {
     "rt_reset_counters": (C.c_int, [_VP]),
     "rt_set_partition": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
     "rt_accum_device_ptr": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_size_t)]),
+    "rt_bind_accum": (C.c_int, [_VP, _VP, C.c_size_t]),
     "rt_set_stream": (C.c_int, [_VP, _VP]),
     "rt_clear": (C.c_int, [_VP]),
     "rt_enable_timing": (C.c_int, [_VP, C.c_int]),

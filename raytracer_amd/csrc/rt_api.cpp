@@ -34,7 +34,8 @@ struct rt_ctx {
   int device = 0;
   uint32_t width = 0, height = 0, flags = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
-  void* accum = nullptr;
+  void* accum = nullptr;      // image in use (own_accum or caller-bound memory)
+  void* own_accum = nullptr;
   size_t accum_bytes = 0;
   uint32_t* rng = nullptr;  // allocated on first rt_enable_rng_capture
   bool rng_capture = false;
@@ -161,7 +162,8 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   const size_t px = (size_t)width * height;
   c->accum_bytes = px * ((flags & RT_ACCUM_F32) ? 16u : 4u);
   hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipMalloc(&c->accum, c->accum_bytes);
+  if (e == hipSuccess) e = hipMalloc(&c->own_accum, c->accum_bytes);
+  c->accum = c->own_accum;
   if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 12 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
   if (e == hipSuccess) {
@@ -188,7 +190,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipEventDestroy(ev.second);
   }
   if (c->time_copied) (void)hipEventDestroy(c->time_copied);
-  (void)hipFree(c->accum);
+  (void)hipFree(c->own_accum);
   (void)hipFree(c->rng);
   (void)hipFree(c->counters);
   (void)hipFree(c->sph_test);
@@ -389,6 +391,15 @@ int rt_accum_device_ptr(rt_ctx* ctx, void** dptr, size_t* bytes) {
   if (!dptr || !bytes) return fail(RT_ERR_INVALID, "null out pointer");
   *dptr = ctx->accum;
   *bytes = ctx->accum_bytes;
+  return RT_OK;
+}
+
+int rt_bind_accum(rt_ctx* ctx, void* dptr, size_t bytes) {
+  if (int rc = check(ctx)) return rc;
+  if (dptr && bytes != ctx->accum_bytes) return fail(RT_ERR_INVALID, "rt_bind_accum: size must equal the image size");
+  if (dptr && (reinterpret_cast<uintptr_t>(dptr) & 15u)) return fail(RT_ERR_INVALID, "rt_bind_accum: need 16-byte alignment");
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->accum = dptr ? dptr : ctx->own_accum;
   return RT_OK;
 }
 

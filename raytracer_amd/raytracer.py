@@ -134,6 +134,9 @@ class Raytracer:
         check(self._lib.rt_accum_device_ptr(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def bind_accum(self, device_ptr, nbytes):
+        check(self._lib.rt_bind_accum(self._h, C.c_void_p(device_ptr), nbytes))
+
     def enable_timing(self, on=True):
         check(self._lib.rt_enable_timing(self._h, int(on)))
 

@@ -1,0 +1,133 @@
+"""GPU: the HIP path against the committed golden vectors (no oracle call needed), and the
+BASELINE configs at full size — C1 complete by checksum, C2 (1080p, 16 spp) one full frame bit for
+bit plus size-independent properties, C4 (1024 spheres) one reduced frame."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import golden_lib as G
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", G.NAMES)
+@pytest.mark.parametrize("batched", [False, True], ids=["per_frame", "batched"])
+def test_hip_reproduces_golden(name, batched):
+    import raytracer_amd as R
+
+    g = G.load(name)
+    rt = R.Raytracer(g["width"], g["height"], g["flags"] | R.RT_MATH_STRICT)
+    rt.set_scene(g["spheres"], g["materials"])
+    rt.enable_rng_capture(True)
+    rt.enable_counters(True)
+    cam = np.array(g["camera"], copy=True)
+    if batched:
+        rt.set_camera(cam)
+        rt.render_frames(g["time_bits"])
+    else:
+        for f in range(g["frames"]):
+            rt.set_time(int(g["time_bits"][f]))
+            rt.set_camera(cam)
+            rt.compute()
+            cam["current_frame"] += 1
+    assert np.array_equal(rt.read_rgba8(), g["rgba8"])
+    assert np.array_equal(rt.read_rng_state(), g["rng"])
+    assert list(rt.counters().values()) == [int(x) for x in g["counters"]]
+    if "accum" in g:
+        assert np.array_equal(rt.read_accum_f32().view(np.uint32), g["accum"].view(np.uint32))
+    rt.close()
+
+
+def test_c1_complete_checksum_through_the_host_app():
+    """BASELINE config 1 in full through the C++ App mirror (update/render x 64), RGBA8 recurrence."""
+    import raytracer_amd as R
+    from raytracer_amd import host
+
+    want = G.checksums()["C1_640x360_1spp_64frames"]
+    spheres, mats = host.scene_default(1)
+    for batched in (False, True):
+        app = host.App(640, 360, R.RT_ACCUM_RGBA8, spheres, mats, spp=1, frames=64)
+        (app.run if batched else app.redraw)(64)
+        img = app.read_rgba8()
+        assert app.current_frame == 64 and app.time_bits == 0x3F23D705
+        assert hashlib.sha256(img.tobytes()).hexdigest() == want["rgba8_sha256"]
+        assert not img[352:].any()  # rows the floor(h/16) dispatch never covers
+        app.close()
+
+
+def test_c2_full_size_frame_bit_exact_and_properties():
+    """BASELINE config 2 geometry (1920x1080, 16 spp): frames 0 and 3 against the oracle bit for bit
+    (every pixel's RNG state and the RGBA8 image), then properties on a longer batched run."""
+    import raytracer_amd as R
+    from raytracer_amd import host
+
+    W, H, spp = 1920, 1080, 16
+    spheres, mats = host.scene_default(1)
+    tb = host.time_table(8)
+    rt = R.Raytracer(W, H, R.RT_ACCUM_RGBA8)
+    rt.set_scene(spheres, mats)
+    rt.enable_rng_capture(True)
+    img = O.OracleImage(W, H, 0)
+    for f in (0, 3):
+        cam = host.camera_raw(W, H, spp=spp, frames=256, current_frame=f)
+        rt.set_time(int(tb[f])); rt.set_camera(cam); rt.compute()
+        O.compute(img, spheres, mats, cam, int(tb[f]))
+        assert np.array_equal(rt.read_rng_state(), img.rng), f"frame {f}"
+        assert np.array_equal(rt.read_rgba8(), img.rgba8), f"frame {f}"
+    # KAT from SURVEY.md §8c: pixel (1919,1071) of frame 3 starts from seed 0x83646972
+    assert img.rng[1071, 1919] != 0
+    out = rt.read_rgba8()
+    assert not out[1072:].any() and (out[:1072, :, 3] == 255).all()  # 1080/16 = 67.5 -> rows 1072.. untouched
+    rt.close()
+    # batched 8-frame run == 8 single launches (idempotent schedule), and is deterministic
+    a = R.Raytracer(W, H, R.RT_ACCUM_RGBA8); a.set_scene(spheres, mats); a.enable_rng_capture(True)
+    b = R.Raytracer(W, H, R.RT_ACCUM_RGBA8); b.set_scene(spheres, mats); b.enable_rng_capture(True)
+    cam = host.camera_raw(W, H, spp=2, frames=8)
+    a.set_camera(cam); a.render_frames(tb)
+    for f in range(8):
+        b.set_time(int(tb[f])); b.set_camera(cam); b.compute(); cam["current_frame"] += 1
+    assert np.array_equal(a.read_rgba8(), b.read_rgba8()) and np.array_equal(a.read_rng_state(), b.read_rng_state())
+    a.close(); b.close()
+
+
+def test_c4_1024_spheres_frame_bit_exact():
+    """BASELINE config 4 scene (random_bunch(1024), 16 materials) at 1080p, 1 spp, one frame."""
+    import raytracer_amd as R
+    from raytracer_amd import host
+
+    W, H = 1920, 1080
+    spheres, mats = host.scene_random_bunch(1024, 16, 4)
+    cam = host.camera_raw(W, H, spp=1, frames=16)
+    tb = host.time_table(1)
+    rt = R.Raytracer(W, H, R.RT_ACCUM_F32)
+    rt.set_scene(spheres, mats); rt.enable_rng_capture(True); rt.enable_counters(True)
+    rt.set_time(int(tb[0])); rt.set_camera(cam); rt.compute()
+    img = O.OracleImage(W, H, O.ACCUM_F32)
+    O.compute(img, spheres, mats, cam, int(tb[0]))
+    assert np.array_equal(rt.read_rng_state(), img.rng)
+    assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
+    assert rt.counters() == img.counters_dict()
+    rt.close()
+
+
+def test_c3_checker_4k_tile_band_bit_exact():
+    """BASELINE config 3 (3840x2160, 64 spp, checker scene): 1/16 of the tiles of one frame against the
+    oracle (tile split rank 5 of 16), bit for bit."""
+    import raytracer_amd as R
+    from raytracer_amd import host
+
+    W, H, spp = 3840, 2160, 64
+    spheres, mats = host.scene_random_bunch(20, 3, 3)
+    cam = host.camera_raw(W, H, spp=spp, frames=8)
+    tb = host.time_table(1)
+    flags = R.RT_ACCUM_F32 | R.RT_SHADE_CHECKER
+    rt = R.Raytracer(W, H, flags)
+    rt.set_scene(spheres, mats); rt.set_partition(5, 16); rt.enable_rng_capture(True)
+    rt.set_time(int(tb[0])); rt.set_camera(cam); rt.compute()
+    img = O.OracleImage(W, H, O.ACCUM_F32 | O.SHADE_CHECKER)
+    O.compute(img, spheres, mats, cam, int(tb[0]), rank=5, world=16)
+    assert np.array_equal(rt.read_rng_state(), img.rng)
+    assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
+    rt.close()
