@@ -99,6 +99,9 @@ typedef struct rt_counters {
   uint64_t N;  /* samples (paths)                                                   */
   uint64_t P;  /* pixel-frames                                                      */
   uint64_t rand_calls;
+  /* lane-occupancy diagnostics of the HIP kernel (0 in the oracle): 64 x wave iterations */
+  uint64_t slots_trace;  /* 64 x (wave loop iterations that ran the hit loop): R / slots_trace = hit-loop lane occupancy */
+  uint64_t slots_reject; /* 64 x (rejection rounds run): J / slots_reject = rejection lane occupancy */
 } rt_counters;
 
 #ifdef __cplusplus

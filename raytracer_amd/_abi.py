@@ -29,10 +29,17 @@ RT_ERR_NO_DEVICE = -4
 
 
 class RtCounters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("T", "D", "H", "R", "M", "S", "Sm", "J", "Sd", "N", "P", "rand_calls")]
+    _fields_ = [(n, C.c_uint64) for n in ("T", "D", "H", "R", "M", "S", "Sm", "J", "Sd", "N", "P", "rand_calls", "slots_trace", "slots_reject")]
+
+    EVENTS = ("T", "D", "H", "R", "M", "S", "Sm", "J", "Sd", "N", "P", "rand_calls")
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        """The twelve event counters the oracle also keeps."""
+        return {n: int(getattr(self, n)) for n in self.EVENTS}
+
+    def occupancy(self):
+        """Lane-occupancy diagnostics of the kernel."""
+        return {"slots_trace": int(self.slots_trace), "slots_reject": int(self.slots_reject)}
 
 
 # name -> (restype, argtypes); every symbol include/rt_hip.h declares

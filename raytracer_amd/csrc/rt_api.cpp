@@ -3,7 +3,9 @@
 // fallback anywhere in this library: without a gfx950 device rt_create fails.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -40,6 +42,10 @@ struct rt_ctx {
   uint32_t* rng = nullptr;  // allocated on first rt_enable_rng_capture
   bool rng_capture = false;
   unsigned long long* counters = nullptr;
+  uint32_t* queue = nullptr;  // tile queue head of the persistent kernel
+  int compute_units = 0;
+  int waves_per_cu = 0;       // launch width override (0 = default); env RT_WAVES_PER_CU
+  int reject_tries = 0;       // rejection rounds override (0 = default); env RT_REJECT_TRIES
   bool counting = false;
   rt_f32x4 *sph_test = nullptr, *sph_shade = nullptr, *sph_col = nullptr;
   uint32_t n_spheres = 0;
@@ -106,8 +112,19 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.accum = ctx->accum;
   a.rng_out = ctx->rng_capture ? ctx->rng : nullptr;
   a.counters = ctx->counters;
+  a.queue = ctx->queue;
   if (a.n_tiles == 0) return RT_OK;
   const uint32_t my_tiles = a.n_tiles > a.rank ? (a.n_tiles - a.rank + a.world - 1u) / a.world : 0u;
+  a.my_tiles = my_tiles;
+  if (my_tiles == 0) return RT_OK;
+  // Rejection rounds per iteration: a lane that sits out pays one trace, so allow more rounds
+  // the more a trace costs ("bounded rejection").
+  a.reject_tries = a.n_spheres <= 8u ? 2u : (a.n_spheres <= 64u ? 3u : 64u);
+  if (ctx->reject_tries > 0) a.reject_tries = (uint32_t)ctx->reject_tries;
+  // Persistent launch: enough single-wave workgroups to fill every SIMD, never more than tiles.
+  const uint32_t wpc = ctx->waves_per_cu > 0 ? (uint32_t)ctx->waves_per_cu : 32u;
+  const uint64_t resident = (uint64_t)ctx->compute_units * wpc;
+  const uint32_t n_waves = (uint32_t)(resident < my_tiles ? resident : my_tiles);
   // host-side shape check before the launch: every tile index a block can form is < n_tiles or
   // rejected by the kernel's own guard; every pixel index is < width*height by construction of cov_*
   if (a.cov_w > a.width || a.cov_h > a.height) return fail(RT_ERR_INVALID, "covered area exceeds the image");
@@ -124,7 +141,8 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     RT_HIP(hipEventRecord(e0, ctx->stream));
   }
   const bool strict = (ctx->flags & RT_MATH_FAST) == 0;
-  RT_HIP(rt_launch_path_kernel(a, my_tiles, strict, ctx->counting, ctx->stream));
+  RT_HIP(hipMemsetAsync(ctx->queue, 0, sizeof(uint32_t), ctx->stream));
+  RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, ctx->stream));
   if (ctx->timing) RT_HIP(hipEventRecord(e1, ctx->stream));
   return RT_OK;
 }
@@ -164,13 +182,17 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&c->own_accum, c->accum_bytes);
   c->accum = c->own_accum;
-  if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 12 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 14 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->queue, sizeof(uint32_t));
+  c->compute_units = prop.multiProcessorCount;
+  if (const char* e1 = std::getenv("RT_WAVES_PER_CU")) c->waves_per_cu = std::atoi(e1);   // tuning knobs for experiments
+  if (const char* e2 = std::getenv("RT_REJECT_TRIES")) c->reject_tries = std::atoi(e2);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
   if (e == hipSuccess) {
     c->stream = c->own_stream;
     e = hipMemsetAsync(c->accum, 0, c->accum_bytes, c->stream);
   }
-  if (e == hipSuccess) e = hipMemsetAsync(c->counters, 0, 12 * sizeof(unsigned long long), c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(c->counters, 0, 14 * sizeof(unsigned long long), c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) {
     const std::string msg = std::string("rt_create: ") + hipGetErrorString(e);
@@ -193,6 +215,7 @@ void rt_destroy(rt_ctx* c) {
   (void)hipFree(c->own_accum);
   (void)hipFree(c->rng);
   (void)hipFree(c->counters);
+  (void)hipFree(c->queue);
   (void)hipFree(c->sph_test);
   (void)hipFree(c->sph_shade);
   (void)hipFree(c->sph_col);
@@ -217,7 +240,11 @@ int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, cons
     // fl(r*r) is the same single rounding the shader performs per test (wgsl:210); hoisting it is bit-safe
     const volatile float r = s.radius;
     const float rr = r * r;
-    const float inv_r = 1.0f / r;
+    // sph_col.w = +1/r when r is a power of two (then x / r == x * (1/r) exactly and the strict
+    // kernel multiplies), -1/r otherwise (it divides); the fast kernel uses |sph_col.w|.
+    int ex = 0;
+    const bool pow2 = r > 0.0f && std::frexp((float)r, &ex) == 0.5f && ex > -100 && ex < 100;
+    const float inv_r = pow2 ? 1.0f / r : -std::fabs(1.0f / r);
     test[i] = rt_f32x4{s.center[0], s.center[1], s.center[2], rr};
     shade[i] = rt_f32x4{s.center[0], s.center[1], s.center[2], s.radius};
     col[i] = rt_f32x4{m.color[0], m.color[1], m.color[2], inv_r};
@@ -364,17 +391,18 @@ int rt_enable_counters(rt_ctx* ctx, int enable) {
 int rt_get_counters(rt_ctx* ctx, rt_counters* out) {
   if (int rc = check(ctx)) return rc;
   if (!out) return fail(RT_ERR_INVALID, "out is null");
-  unsigned long long h[12];
+  unsigned long long h[14];
   RT_HIP(hipMemcpyAsync(h, ctx->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   RT_HIP(hipStreamSynchronize(ctx->stream));
   out->T = h[0]; out->D = h[1]; out->H = h[2]; out->R = h[3]; out->M = h[4]; out->S = h[5];
   out->Sm = h[6]; out->J = h[7]; out->Sd = h[8]; out->N = h[9]; out->P = h[10]; out->rand_calls = h[11];
+  out->slots_trace = h[12]; out->slots_reject = h[13];
   return RT_OK;
 }
 
 int rt_reset_counters(rt_ctx* ctx) {
   if (int rc = check(ctx)) return rc;
-  RT_HIP(hipMemsetAsync(ctx->counters, 0, 12 * sizeof(unsigned long long), ctx->stream));
+  RT_HIP(hipMemsetAsync(ctx->counters, 0, 14 * sizeof(unsigned long long), ctx->stream));
   return RT_OK;
 }
 

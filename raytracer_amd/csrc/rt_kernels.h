@@ -17,6 +17,8 @@ struct rt_kargs {
   uint32_t cov_w, cov_h;    // pixels a pass covers (floor16 or full)
   uint32_t tiles_x, n_tiles;  // 8x8 tiles over the covered area
   uint32_t rank, world;     // tile t belongs to this launch iff t % world == rank
+  uint32_t my_tiles;        // number of tiles of this rank: tile = j * world + rank, j < my_tiles
+  uint32_t reject_tries;    // rejection-sampling rounds per loop iteration (>= 1)
   uint32_t spp;
   uint32_t first_frame, n_frames;
   uint32_t time_bits0;           // time bits of the first frame
@@ -28,8 +30,10 @@ struct rt_kargs {
   const rt_f32x4* sph_col;
   void* accum;                   // RGBA8: uint32 per pixel; F32: float4 per pixel
   uint32_t* rng_out;             // optional
-  unsigned long long* counters;  // 12 x u64, COUNT variants only
+  unsigned long long* counters;  // 14 x u64, COUNT variants only
+  uint32_t* queue;               // tile queue head, zeroed on the stream before every launch
 };
 
-hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t my_tiles, bool strict, bool count, hipStream_t stream);
+// n_waves persistent single-wave workgroups pull tiles from a.queue until a.my_tiles are handed out
+hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, hipStream_t stream);
 hipError_t rt_launch_quantize(const void* src_f32x4, void* dst_rgba8, size_t n_pixels, hipStream_t stream);

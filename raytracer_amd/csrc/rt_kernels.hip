@@ -4,23 +4,30 @@
 // and the buffer->cache copy of Raytracer::compute (src/raytracing.rs:195-199). Written for CDNA4,
 // not translated from the shader:
 //
-//  * one 64-lane wavefront = one 8x8 pixel tile (one pixel per lane): primary rays of a wave stay
-//    coherent on sphere silhouettes, and each 8-pixel row of float4 accumulators is one 128-B line;
-//  * workgroup = 1 wave: no barriers, the dispatcher balances tiles of very different cost;
-//  * the sample loop, the bounce loop and (in batched launches) the frame loop of a pixel are
-//    FLATTENED into one loop of trace() iterations with path regeneration: a lane whose path ends
-//    starts its next sample (or next frame) in the same iteration, so a wave runs for
-//    max-over-lanes of TOTAL trace calls instead of sum-over-samples of max-over-lanes of path
-//    length. Each lane still consumes its own RNG stream in the reference's order.
-//  * the sphere index of the hit loop is wave-uniform: test data {cx,cy,cz,r*r} is read with
-//    scalar loads (s_load_dwordx4/x8/x16 through the constant address space) and used straight
-//    from SGPRs; only the winning sphere's shading data is fetched per lane;
-//  * the accumulation image is read once and written once per launch, in place.
+//  * PERSISTENT WAVES, STREAMED PIXELS. The launch is sized to the chip (a few waves per SIMD), not
+//    to the image. A wave pulls 8x8-pixel tiles from a global queue (one atomic per 64 pixels) and
+//    hands their pixels to its lanes one by one: a lane that finishes a pixel takes the next one
+//    immediately. Lanes therefore stay busy although pixels differ 3x in cost (sky = 1 trace per
+//    sample, mirror chains = up to 11), and the chip drains within one pixel's work of the end.
+//  * ONE FLAT LOOP PER LANE. Frame loop, sample loop and bounce loop of a pixel are flattened into
+//    a loop of trace() iterations with path regeneration. Every lane still consumes its own RNG
+//    stream in the reference's order, so results do not depend on which lane renders a pixel.
+//  * TWO-PHASE HIT LOOP. Phase 1 walks the spheres with a wave-uniform index: test data
+//    {cx,cy,cz,r*r} arrives by scalar loads and is used straight from SGPRs, 12 VALU ops per
+//    sphere, no branch; the sign bit of a conservative discriminant is shifted into a per-lane
+//    32-sphere bitmask (v_alignbit). Phase 2 lets every lane walk ITS OWN candidate bits (gathered
+//    loads), so the expensive root code (sqrt, divisions) runs at full lane occupancy instead of
+//    once per sphere that any lane of the wave might hit.
+//  * BOUNDED REJECTION SAMPLING. random_in_unit_sphere (p = pi/6) runs at most `reject_tries`
+//    rounds per iteration; lanes still without a direction sit out one trace instead of making 63
+//    lanes wait for the unluckiest one.
+//  * The accumulation image is read once and written once per pixel and launch, in place.
 //
-// Two arithmetic modes (rt_types.h): RT_MATH_STRICT restates the oracle's IEEE contract operation
-// by operation (bit-identical images and RNG states); RT_MATH_FAST uses FMA, v_rcp/v_rsq/v_sqrt and
-// dot() for length_squared.  This file must be compiled with -ffp-contract=off: every fused
-// operation below is written explicitly.
+// Two arithmetic modes (rt_types.h). RT_MATH_STRICT: phase 2, shading and accumulation restate
+// the oracle's IEEE contract operation by operation (bit-identical images and RNG states); phase 1
+// only has to be a superset filter, so it shares the fast FMA form plus a proven error margin.
+// RT_MATH_FAST: FMA, v_rcp/v_rsq/v_sqrt, dot() for length_squared.
+// This file must be compiled with -ffp-contract=off: every fused operation is written explicitly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,6 +39,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) f32x4* const_f32x4_ptr;  // scalar-load path
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 // raytrace_kernal.wgsl:265-275 (state update) — integer, bit-exact in every mode
 __device__ __forceinline__ uint32_t rng_step(uint32_t rng) {
@@ -70,223 +78,47 @@ __device__ __forceinline__ uint32_t unorm8(float x) {  // rgba8unorm store: clam
   return (uint32_t)__builtin_rintf(c * 255.0f);
 }
 
+enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_READY = 2, ST_NEED_DIR = 3, ST_NEW_RAY = 4, ST_PATH_DONE = 5, ST_GOT_DIR = 6 };
+
 template <bool STRICT, bool COUNT>
 __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
   const uint32_t lane = threadIdx.x;
-  const uint32_t tile = blockIdx.x * a.world + a.rank;
-  if (tile >= a.n_tiles) return;
-  const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-  const uint32_t u = tx * 8u + (lane & 7u);
-  const uint32_t v = ty * 8u + (lane >> 3);
-  if (u >= a.cov_w || v >= a.cov_h) return;  // only in RT_DISPATCH_FULL with ragged edges
-
   const bool checker = (a.flags & RT_SHADE_CHECKER) != 0;
   const bool accum_f32 = (a.flags & RT_ACCUM_F32) != 0;
   const bool combine_sum = (a.flags & RT_COMBINE_SUM) != 0;
-
-  // ---- pixel_to_world / get_pixel_delta (wgsl:85-94): once per pixel, frame-invariant ---------
   const float* m = a.p2w;  // column-major
-  float pcx, pcy, pcz, pdx, pdy, pdz;
-  {
-    const float vx = (float)u, vy = (float)(a.height - v);
-    const float wx = (float)(u + 1u), wy = (float)(a.height - (v + 1u));
-    pcx = ((m[0] * vx + m[4] * vy) + m[8] * 0.0f) + m[12] * 1.0f;
-    pcy = ((m[1] * vx + m[5] * vy) + m[9] * 0.0f) + m[13] * 1.0f;
-    pcz = ((m[2] * vx + m[6] * vy) + m[10] * 0.0f) + m[14] * 1.0f;
-    const float nx = ((m[0] * wx + m[4] * wy) + m[8] * 0.0f) + m[12] * 1.0f;
-    const float ny = ((m[1] * wx + m[5] * wy) + m[9] * 0.0f) + m[13] * 1.0f;
-    const float nz = ((m[2] * wx + m[6] * wy) + m[10] * 0.0f) + m[14] * 1.0f;
-    pdx = nx - pcx; pdy = ny - pcy; pdz = nz - pcz;
-  }
-
-  // ---- accumulator: read once ------------------------------------------------------------------
-  const size_t pix = (size_t)v * a.width + u;
-  float acc0, acc1, acc2, acc3;
-  if (accum_f32) {
-    const f32x4 c = reinterpret_cast<const f32x4*>(a.accum)[pix];
-    acc0 = c.x; acc1 = c.y; acc2 = c.z; acc3 = c.w;
-  } else {
-    const uint32_t q = reinterpret_cast<const uint32_t*>(a.accum)[pix];
-    acc0 = (float)(q & 255u) / 255.0f; acc1 = (float)((q >> 8) & 255u) / 255.0f;
-    acc2 = (float)((q >> 16) & 255u) / 255.0f; acc3 = (float)(q >> 24) / 255.0f;
-  }
-
   const const_f32x4_ptr sph_test = (const_f32x4_ptr)(uintptr_t)a.sph_test;
   const uint32_t n_spheres = a.n_spheres;
   const float spp_f = (float)a.spp;
 
   uint32_t c_T = 0, c_D = 0, c_H = 0, c_R = 0, c_M = 0, c_S = 0, c_Sm = 0, c_J = 0, c_Sd = 0, c_N = 0, c_P = 0, c_rand = 0;
+  uint32_t c_wt = 0, c_wr = 0;  // wave-level iteration counts (diagnostics)
 
-  // ---- flattened frame x sample x bounce loop ------------------------------------------------
-  uint32_t k = 0;  // frame within this launch
-  uint32_t rng = rng_seed(u, v, a.time_table ? a.time_table[0] : a.time_bits0);
-  rng = rng_step(rng);  // initialize_rng's discarded rand() (wgsl:262)
-  if (COUNT) c_rand++;
-  uint32_t sample = 0;
-  float sumx = 0.0f, sumy = 0.0f, sumz = 0.0f;  // send_rays' `color`
-  float ox, oy, oz, dx, dy, dz;                // ray
-  float colx, coly, colz, refl;                // ray_color's `color`, `reflectance`
-  uint32_t depth;
-  {  // get_random_ray (wgsl:174-180) for sample 0
-    float r0, r1;
-    RT_RAND(r0); RT_RAND(r1);
-    const float px = -0.5f + r0, py = -0.5f + r1;
-    dx = pcx + px * pdx; dy = pcy + py * pdy; dz = pcz + 1.0f * pdz;
-    ox = a.pos[0]; oy = a.pos[1]; oz = a.pos[2];
-    colx = coly = colz = 0.0f; refl = 1.0f; depth = 0;
-    if (COUNT) c_N++;
-  }
+  // wave-uniform work queue: pixel slots [q_cur, q_end) of the tile this wave is handing out.
+  // slot = (index of the tile in this rank's tile list) * 64 + (pixel within the 8x8 tile)
+  uint32_t q_cur = 0, q_end = 0;
+  bool more = true;
 
-  bool alive = true;
-  while (alive) {
-    // ================= trace (wgsl:182-231) =================
-    float closest = RT_RAY_TMAX;
-    int hit = -1;
-    float aa, inv_a;
-    if (STRICT) {
-      const float len = __builtin_sqrtf(dot_strict(dx, dy, dz, dx, dy, dz));
-      aa = len * len;  // length_squared (wgsl:306-309)
-      inv_a = 0.0f;
-    } else {
-      aa = dot_fast(dx, dy, dz, dx, dy, dz);
-      inv_a = __builtin_amdgcn_rcpf(aa);
-    }
-    if (COUNT) { c_R++; c_T += n_spheres; }
-#pragma unroll 4
-    for (uint32_t i = 0; i < n_spheres; ++i) {
-      const f32x4 s = sph_test[i];  // {cx, cy, cz, r*r}: wave-uniform -> SGPRs
-      const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
-      if (STRICT) {
-        const float hb = dot_strict(ocx, ocy, ocz, dx, dy, dz);
-        const float ss = dot_strict(ocx, ocy, ocz, ocx, ocy, ocz);
-        // Exact-arithmetic filter. The oracle's c = fl(fl(sqrt(ss))^2) - rr differs from ss - rr by
-        // less than (ss+rr)*2^-21, so fl(a*c) differs from fl(a*(ss-rr)) by less than
-        // a*(ss+rr)*2^-20.5. If the cheap discriminant is below -a*(ss+rr)*2^-19 the exact one is
-        // negative too (a certain miss) and the two IEEE square roots are skipped. Anything else —
-        // including NaN/inf, for which the comparison is false — takes the exact path.
-        const float hb2 = hb * hb;
-        const float dt = hb2 - aa * (ss - s.w);
-        const float margin = __builtin_fmaf((ss + s.w) * aa, 0x1p-19f, 1e-30f);
-        if (!(dt < -margin)) {
-          const float len = __builtin_sqrtf(ss);
-          const float c = len * len - s.w;
-          const float disc = hb2 - aa * c;
-          if (!(disc < 0.0f)) {
-            if (COUNT) c_D++;
-            const float sq = __builtin_sqrtf(disc);
-            float root = (-hb - sq) / aa;
-            bool ok = true;
-            if (root <= RT_RAY_TMIN || closest <= root) {
-              root = (-hb + sq) / aa;
-              if (root <= RT_RAY_TMIN || closest <= root) ok = false;
-            }
-            if (ok) { closest = root; hit = (int)i; }
-          }
-        }
-      } else {
-        const float hb = dot_fast(ocx, ocy, ocz, dx, dy, dz);
-        const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
-        const float disc = __builtin_fmaf(-aa, cc, hb * hb);
-        if (!(disc < 0.0f)) {
-          if (COUNT) c_D++;
-          const float sq = __builtin_amdgcn_sqrtf(disc);
-          float root = (-hb - sq) * inv_a;
-          bool ok = true;
-          if (root <= RT_RAY_TMIN || closest <= root) {
-            root = (-hb + sq) * inv_a;
-            if (root <= RT_RAY_TMIN || closest <= root) ok = false;
-          }
-          if (ok) { closest = root; hit = (int)i; }
-        }
-      }
-    }
+  // per-lane state machine:
+  //   NEED_PIXEL -[A]-> NEW_RAY -[G]-> READY -[C]-> PATH_DONE (miss / depth) | READY (mirror) | NEED_DIR (diffuse)
+  //   NEED_DIR -[G]-> GOT_DIR -> READY | PATH_DONE ;  PATH_DONE -[E]-> NEW_RAY | NEED_PIXEL ;  NEED_PIXEL -[A]-> DEAD when the queue is empty
+  uint32_t state = ST_NEED_PIXEL;
+  uint32_t u = 0, v = 0;
+  float pcx = 0, pcy = 0, pcz = 0, pdx = 0, pdy = 0, pdz = 0;  // pixel_center, pixel_delta
+  float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;                // accumulation pixel
+  uint32_t k = 0, rng = 0, sample = 0, depth = 0;
+  float sumx = 0, sumy = 0, sumz = 0;                          // send_rays' `color`
+  float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;        // ray (in NEED_DIR / GOT_DIR: d holds the normal)
+  float colx = 0, coly = 0, colz = 0, refl = 1.0f;             // ray_color's `color`, `reflectance`
+  float gqx = 0, gqy = 0, gqz = 0, gl2 = 1.0f;                 // accepted point of random_in_unit_sphere, |q|^2
 
-    // ================= shade =================
-    bool end_path;
-    if (hit < 0) {
-      // miss (wgsl:144-148); ray_color: color += miss * reflectance; break
-      if (COUNT) c_M++;
-      if (!checker) {
-        const float t = 0.5f * (1.0f - dy);
-        const float it = 1.0f - t;
-        colx = colx + (it + t * 0.5f) * refl;
-        coly = coly + (it + t * 0.7f) * refl;
-        colz = colz + (it + t * 1.0f) * refl;
-      } else {
-        colx = colx + 0.0f * refl; coly = coly + 0.0f * refl; colz = colz + 0.0f * refl;
-      }
-      end_path = true;
-    } else {
-      if (COUNT) { c_H++; c_S++; }
-      const f32x4 sg = a.sph_shade[hit];  // {cx, cy, cz, r}
-      const f32x4 sc = a.sph_col[hit];    // {material r, g, b, 1/r}
-      // hit record of the closest sphere (wgsl:225-227): point = ray_at(t), normal = (point - c) / r
-      float px, py, pz, nx, ny, nz;
-      if (STRICT) {
-        px = ox + closest * dx; py = oy + closest * dy; pz = oz + closest * dz;
-        nx = (px - sg.x) / sg.w; ny = (py - sg.y) / sg.w; nz = (pz - sg.z) / sg.w;
-      } else {
-        px = __builtin_fmaf(closest, dx, ox); py = __builtin_fmaf(closest, dy, oy); pz = __builtin_fmaf(closest, dz, oz);
-        nx = (px - sg.x) * sc.w; ny = (py - sg.y) * sc.w; nz = (pz - sg.z) * sc.w;
-      }
-      // scatter (wgsl:150-168)
-      float kk = (1.0f - RT_LOCAL_REFLECTANCE) * refl;
-      if (checker) {
-        const float fx = __builtin_floorf(4.0f * nx);
-        const float fy = __builtin_floorf(4.0f * ny + 0.5f);
-        const float h = (fx + fy) * 0.5f;
-        kk = (h == __builtin_floorf(h)) ? refl : 0.0f;
-      }
-      colx = colx + sc.x * kk; coly = coly + sc.y * kk; colz = colz + sc.z * kk;
-      refl = refl * RT_LOCAL_REFLECTANCE;
-      ox = px; oy = py; oz = pz;
-      if ((hit & 1) == 0) {
-        // reflection (wgsl:170-172): dir - 2*dot(dir, n)*n
-        if (COUNT) c_Sm++;
-        if (STRICT) {
-          const float k2 = 2.0f * dot_strict(dx, dy, dz, nx, ny, nz);
-          dx = dx - k2 * nx; dy = dy - k2 * ny; dz = dz - k2 * nz;
-        } else {
-          const float k2 = -2.0f * dot_fast(dx, dy, dz, nx, ny, nz);
-          dx = __builtin_fmaf(k2, nx, dx); dy = __builtin_fmaf(k2, ny, dy); dz = __builtin_fmaf(k2, nz, dz);
-        }
-      } else {
-        // normal + random_unit_vector() (wgsl:281-294): rejection sampling, 3 rand per try
-        if (COUNT) c_Sd++;
-        float qx, qy, qz, l2;
-        for (;;) {
-          float r0, r1, r2;
-          RT_RAND(r0); RT_RAND(r1); RT_RAND(r2);
-          if (COUNT) c_J++;
-          if (STRICT) {
-            qx = r0 * 2.0f - 1.0f; qy = r1 * 2.0f - 1.0f; qz = r2 * 2.0f - 1.0f;
-            l2 = dot_strict(qx, qy, qz, qx, qy, qz);
-            // accept iff fl(fl(sqrt(l2))^2) < 1. fl(sqrt(.)) is monotone and fl(sqrt(1)) = 1, and
-            // for l2 < 1 the rounded root is <= 1-2^-24 whose square rounds below 1; so the test
-            // equals l2 < 1 exactly (no square root needed).
-            if (l2 < 1.0f) break;
-          } else {
-            qx = __builtin_fmaf(r0, 2.0f, -1.0f); qy = __builtin_fmaf(r1, 2.0f, -1.0f); qz = __builtin_fmaf(r2, 2.0f, -1.0f);
-            l2 = dot_fast(qx, qy, qz, qx, qy, qz);
-            if (l2 < 1.0f) break;
-          }
-        }
-        if (STRICT) {
-          const float len = __builtin_sqrtf(l2);
-          dx = nx + qx / len; dy = ny + qy / len; dz = nz + qz / len;
-        } else {
-          const float il = __builtin_amdgcn_rsqf(l2);
-          dx = __builtin_fmaf(qx, il, nx); dy = __builtin_fmaf(qy, il, ny); dz = __builtin_fmaf(qz, il, nz);
-        }
-      }
-      depth++;
-      end_path = depth > (uint32_t)RT_MAX_RAY_DEPTH;  // for (depth = 0; depth <= MAX_RAY_DEPTH; depth++) (wgsl:131)
-    }
-
-    if (end_path) {
+  for (;;) {
+    // ================= [E] path end: next sample / next frame / next pixel =================
+    if (state == ST_PATH_DONE) {
       // send_rays: color += ray_color(ray) (wgsl:120)
       sumx = sumx + colx; sumy = sumy + coly; sumz = sumz + colz;
       sample++;
+      state = ST_NEW_RAY;
       if (sample == a.spp) {
         // ---- end of this pixel's frame: color / spp (wgsl:122), store_color (wgsl:96-112) ----
         const float p0 = sumx / spp_f, p1 = sumy / spp_f, p2 = sumz / spp_f, p3 = 1.0f;
@@ -299,13 +131,24 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
           const float rw = 1.0f - cw;
           acc0 = p0 * rw + acc0 * cw; acc1 = p1 * rw + acc1 * cw; acc2 = p2 * rw + acc2 * cw; acc3 = p3 * rw + acc3 * cw;
         }
+        uint32_t q8 = 0;
         if (!accum_f32) {  // the reference re-quantises to rgba8unorm every frame (raytracing.rs:30,47)
-          acc0 = (float)unorm8(acc0) / 255.0f; acc1 = (float)unorm8(acc1) / 255.0f;
-          acc2 = (float)unorm8(acc2) / 255.0f; acc3 = (float)unorm8(acc3) / 255.0f;
+          const uint32_t q0 = unorm8(acc0), q1 = unorm8(acc1), q2 = unorm8(acc2), q3 = unorm8(acc3);
+          q8 = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+          acc0 = (float)q0 / 255.0f; acc1 = (float)q1 / 255.0f; acc2 = (float)q2 / 255.0f; acc3 = (float)q3 / 255.0f;
         }
         k++;
         if (k == a.n_frames) {
-          alive = false;
+          // ---- pixel finished: write once, then ask for the next pixel ----
+          const size_t pix = (size_t)v * a.width + u;
+          if (accum_f32) {
+            f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
+            reinterpret_cast<f32x4*>(a.accum)[pix] = o;
+          } else {
+            reinterpret_cast<uint32_t*>(a.accum)[pix] = q8;
+          }
+          if (a.rng_out) a.rng_out[pix] = rng;
+          state = ST_NEED_PIXEL;
         } else {
           rng = rng_seed(u, v, a.time_table[k]);
           rng = rng_step(rng);
@@ -313,33 +156,285 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
           sample = 0; sumx = sumy = sumz = 0.0f;
         }
       }
-      if (alive) {  // path regeneration: get_random_ray for the next sample
-        float r0, r1;
-        RT_RAND(r0); RT_RAND(r1);
+    }
+
+    // ================= [A] hand out pixels =================
+    const unsigned long long need = __ballot(state == ST_NEED_PIXEL);
+    if (need) {
+      const uint32_t n_need = (uint32_t)__popcll(need);
+      const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+      const uint32_t avail = q_end - q_cur;
+      uint32_t slot = q_cur + my;
+      bool got = my < avail;
+      if (n_need > avail) {
+        uint32_t base = 0xffffffffu;
+        if (more) {
+          if (lane == 0) base = atomicAdd(a.queue, 1u);  // all 64 lanes are active here (uniform loop)
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (base >= a.my_tiles) { more = false; base = 0xffffffffu; }
+        }
+        if (base != 0xffffffffu) {
+          if (!got) { slot = base * 64u + (my - avail); got = true; }
+          q_cur = base * 64u + (n_need - avail);
+          q_end = base * 64u + 64u;
+        } else {
+          q_cur = q_end;
+        }
+      } else {
+        q_cur += n_need;
+      }
+      if (state == ST_NEED_PIXEL) {
+        if (!got) {
+          state = ST_DEAD;
+        } else {
+          const uint32_t tile = (slot >> 6) * a.world + a.rank;
+          const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+          u = tx * 8u + (slot & 7u);
+          v = ty * 8u + ((slot >> 3) & 7u);
+          if (u < a.cov_w && v < a.cov_h) {  // false only on ragged edges in RT_DISPATCH_FULL: take another slot next round
+            // pixel_to_world / get_pixel_delta (wgsl:85-94)
+            const float vx = (float)u, vy = (float)(a.height - v);
+            const float wx = (float)(u + 1u), wy = (float)(a.height - (v + 1u));
+            pcx = ((m[0] * vx + m[4] * vy) + m[8] * 0.0f) + m[12] * 1.0f;
+            pcy = ((m[1] * vx + m[5] * vy) + m[9] * 0.0f) + m[13] * 1.0f;
+            pcz = ((m[2] * vx + m[6] * vy) + m[10] * 0.0f) + m[14] * 1.0f;
+            const float nx = ((m[0] * wx + m[4] * wy) + m[8] * 0.0f) + m[12] * 1.0f;
+            const float ny = ((m[1] * wx + m[5] * wy) + m[9] * 0.0f) + m[13] * 1.0f;
+            const float nz = ((m[2] * wx + m[6] * wy) + m[10] * 0.0f) + m[14] * 1.0f;
+            pdx = nx - pcx; pdy = ny - pcy; pdz = nz - pcz;
+            const size_t pix = (size_t)v * a.width + u;
+            if (accum_f32) {
+              const f32x4 c = reinterpret_cast<const f32x4*>(a.accum)[pix];
+              acc0 = c.x; acc1 = c.y; acc2 = c.z; acc3 = c.w;
+            } else {
+              const uint32_t q = reinterpret_cast<const uint32_t*>(a.accum)[pix];
+              acc0 = (float)(q & 255u) / 255.0f; acc1 = (float)((q >> 8) & 255u) / 255.0f;
+              acc2 = (float)((q >> 16) & 255u) / 255.0f; acc3 = (float)(q >> 24) / 255.0f;
+            }
+            k = 0;
+            rng = rng_seed(u, v, a.time_table ? a.time_table[0] : a.time_bits0);
+            rng = rng_step(rng);  // initialize_rng's discarded rand() (wgsl:262)
+            if (COUNT) c_rand++;
+            sample = 0; sumx = sumy = sumz = 0.0f;
+            state = ST_NEW_RAY;
+          }
+        }
+      }
+    }
+    if (!__ballot(state != ST_DEAD)) break;  // every lane drained and the queue is empty
+
+    // ================= [G] random draws =================
+    // Round 0 is shared: lanes starting a sample draw the two jitter numbers of get_random_ray
+    // (wgsl:174-180) with the same instructions that give lanes in random_in_unit_sphere
+    // (wgsl:281-290) the first two of their three numbers. Further rounds serve NEED_DIR only.
+    if (state == ST_NEW_RAY || state == ST_NEED_DIR) {
+      float r0, r1;
+      RT_RAND(r0); RT_RAND(r1);
+      if (state == ST_NEW_RAY) {
         const float px = -0.5f + r0, py = -0.5f + r1;
         dx = pcx + px * pdx; dy = pcy + py * pdy; dz = pcz + 1.0f * pdz;
         ox = a.pos[0]; oy = a.pos[1]; oz = a.pos[2];
         colx = coly = colz = 0.0f; refl = 1.0f; depth = 0;
         if (COUNT) c_N++;
+        state = ST_READY;
+      } else {
+        float r2;
+        RT_RAND(r2);
+        if (COUNT) c_J++;
+        float qx, qy, qz, l2;
+        if (STRICT) {
+          qx = r0 * 2.0f - 1.0f; qy = r1 * 2.0f - 1.0f; qz = r2 * 2.0f - 1.0f;
+          l2 = dot_strict(qx, qy, qz, qx, qy, qz);
+        } else {
+          qx = __builtin_fmaf(r0, 2.0f, -1.0f); qy = __builtin_fmaf(r1, 2.0f, -1.0f); qz = __builtin_fmaf(r2, 2.0f, -1.0f);
+          l2 = dot_fast(qx, qy, qz, qx, qy, qz);
+        }
+        // STRICT: accept iff fl(fl(sqrt(l2))^2) < 1 (wgsl:284,306-309). fl(sqrt(.)) is monotone with
+        // fl(sqrt(1)) = 1, and for l2 <= 1 - 2^-24 the rounded root is <= 1 - 2^-24, whose square
+        // rounds below 1: the test equals l2 < 1 exactly.
+        if (l2 < 1.0f) { gqx = qx; gqy = qy; gqz = qz; gl2 = l2; state = ST_GOT_DIR; }
+      }
+    }
+    if (COUNT) c_wr++;
+    for (uint32_t round = 1; round < a.reject_tries && __ballot(state == ST_NEED_DIR); ++round) {
+      if (COUNT) c_wr++;
+      if (state == ST_NEED_DIR) {
+        float r0, r1, r2;
+        RT_RAND(r0); RT_RAND(r1); RT_RAND(r2);
+        if (COUNT) c_J++;
+        float qx, qy, qz, l2;
+        if (STRICT) {
+          qx = r0 * 2.0f - 1.0f; qy = r1 * 2.0f - 1.0f; qz = r2 * 2.0f - 1.0f;
+          l2 = dot_strict(qx, qy, qz, qx, qy, qz);
+        } else {
+          qx = __builtin_fmaf(r0, 2.0f, -1.0f); qy = __builtin_fmaf(r1, 2.0f, -1.0f); qz = __builtin_fmaf(r2, 2.0f, -1.0f);
+          l2 = dot_fast(qx, qy, qz, qx, qy, qz);
+        }
+        if (l2 < 1.0f) { gqx = qx; gqy = qy; gqz = qz; gl2 = l2; state = ST_GOT_DIR; }
+      }
+    }
+    if (state == ST_GOT_DIR) {
+      // rec.normal + normalize(p) (wgsl:165,292-294), once per accepted lane after all rounds
+      if (STRICT) {
+        const float len = __builtin_sqrtf(gl2);
+        dx = dx + gqx / len; dy = dy + gqy / len; dz = dz + gqz / len;
+      } else {
+        const float il = __builtin_amdgcn_rsqf(gl2);
+        dx = __builtin_fmaf(gqx, il, dx); dy = __builtin_fmaf(gqy, il, dy); dz = __builtin_fmaf(gqz, il, dz);
+      }
+      state = depth > (uint32_t)RT_MAX_RAY_DEPTH ? ST_PATH_DONE : ST_READY;  // for (depth = 0; depth <= MAX_RAY_DEPTH; depth++) (wgsl:131)
+    }
+
+    // ================= [C] trace + shade (lanes with a ray) =================
+    if (COUNT && __ballot(state == ST_READY)) c_wt++;
+    if (state == ST_READY) {
+      float closest = RT_RAY_TMAX;
+      int hit = -1;
+      const float a_fast = dot_fast(dx, dy, dz, dx, dy, dz);
+      float a_lit = a_fast, inv_a = 0.0f, a_margin = 0.0f;
+      if (STRICT) {
+        const float len = __builtin_sqrtf(dot_strict(dx, dy, dz, dx, dy, dz));
+        a_lit = len * len;  // length_squared (wgsl:306-309)
+        a_margin = a_fast * 0x1p-18f;
+      } else {
+        inv_a = __builtin_amdgcn_rcpf(a_fast);
+      }
+      if (COUNT) { c_R++; c_T += n_spheres; }
+      for (uint32_t base = 0; base < n_spheres; base += 32u) {
+        const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
+        // ---- phase 1: conservative discriminant sign of spheres base..base+cnt-1 -> bitmask ----
+        // bit (cnt-1-j) of `missbits` = sign of sphere (base+j)'s test value (1 = certain miss)
+        uint32_t missbits = 0xffffffffu;
+#pragma unroll 4
+        for (uint32_t j = 0; j < cnt; ++j) {
+          const f32x4 s = sph_test[base + j];  // {cx, cy, cz, r*r}: wave-uniform -> SGPRs
+          const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+          const float hb = dot_fast(ocx, ocy, ocz, dx, dy, dz);
+          const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
+          float test = __builtin_fmaf(-a_fast, cc, hb * hb);
+          if (STRICT) {
+            // |test - exact literal discriminant| < 24 * 2^-24 * a * (|oc|^2 + r^2) ("phase-1
+            // margin"); adding 2^-18 * a * (|oc|^2 + r^2) = a_margin * (cc + 2 r^2) makes a negative
+            // result a certain miss of the oracle's arithmetic too. A NaN produced here is the hardware
+            // default quiet NaN (sign 0), i.e. a candidate for the exact code.
+            test = __builtin_fmaf(a_margin, __builtin_fmaf(2.0f, s.w, cc), test);
+          }
+          missbits = __builtin_amdgcn_alignbit(missbits, as_u32(test), 31);  // (missbits << 1) | sign(test)
+        }
+        // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
+        uint32_t cand = ~missbits;
+        while (cand) {
+          const uint32_t lz = (uint32_t)__builtin_clz(cand);
+          cand &= ~(0x80000000u >> lz);
+          const uint32_t i = base + cnt - 32u + lz;
+          const f32x4 s = a.sph_test[i];
+          const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+          if (STRICT) {
+            // hit_sphere (wgsl:200-231), literal
+            const float hb = dot_strict(ocx, ocy, ocz, dx, dy, dz);
+            const float len = __builtin_sqrtf(dot_strict(ocx, ocy, ocz, ocx, ocy, ocz));
+            const float c = len * len - s.w;
+            const float disc = hb * hb - a_lit * c;
+            if (!(disc < 0.0f)) {
+              if (COUNT) c_D++;
+              const float sq = __builtin_sqrtf(disc);
+              float root = (-hb - sq) / a_lit;
+              bool ok = true;
+              if (root <= RT_RAY_TMIN || closest <= root) {
+                root = (-hb + sq) / a_lit;
+                if (root <= RT_RAY_TMIN || closest <= root) ok = false;
+              }
+              if (ok) { closest = root; hit = (int)i; }
+            }
+          } else {
+            const float hb = dot_fast(ocx, ocy, ocz, dx, dy, dz);
+            const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
+            const float disc = __builtin_fmaf(-a_fast, cc, hb * hb);
+            if (COUNT) c_D++;
+            const float sq = __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.0f));
+            const float r0 = (-hb - sq) * inv_a, r1 = (-hb + sq) * inv_a;
+            const bool ok0 = r0 > RT_RAY_TMIN && r0 < closest;
+            const float root = ok0 ? r0 : r1;
+            if (root > RT_RAY_TMIN && root < closest) { closest = root; hit = (int)i; }
+          }
+        }
+      }
+
+      if (hit < 0) {
+        // miss (wgsl:144-148); ray_color: color += miss * reflectance; break
+        if (COUNT) c_M++;
+        if (!checker) {
+          const float t = 0.5f * (1.0f - dy);
+          const float it = 1.0f - t;
+          colx = colx + (it + t * 0.5f) * refl;
+          coly = coly + (it + t * 0.7f) * refl;
+          colz = colz + (it + t * 1.0f) * refl;
+        } else {
+          colx = colx + 0.0f * refl; coly = coly + 0.0f * refl; colz = colz + 0.0f * refl;
+        }
+        state = ST_PATH_DONE;
+      } else {
+        if (COUNT) { c_H++; c_S++; }
+        const f32x4 sg = a.sph_shade[hit];  // {cx, cy, cz, r}
+        const f32x4 sc = a.sph_col[hit];    // {material r, g, b, +-1/r}
+        // hit record of the closest sphere (wgsl:225-227): point = ray_at(t), normal = (point - c) / r
+        float px, py, pz, nx, ny, nz;
+        if (STRICT) {
+          px = ox + closest * dx; py = oy + closest * dy; pz = oz + closest * dz;
+          const float ex = px - sg.x, ey = py - sg.y, ez = pz - sg.z;
+          if (sc.w > 0.0f) {
+            // r is a power of two (rt_set_scene marks that with a positive 1/r): x / r == x * (1/r)
+            // exactly, barring overflow/underflow of a unit-length normal's components
+            nx = ex * sc.w; ny = ey * sc.w; nz = ez * sc.w;
+          } else {
+            nx = ex / sg.w; ny = ey / sg.w; nz = ez / sg.w;
+          }
+        } else {
+          px = __builtin_fmaf(closest, dx, ox); py = __builtin_fmaf(closest, dy, oy); pz = __builtin_fmaf(closest, dz, oz);
+          const float ir = __builtin_fabsf(sc.w);
+          nx = (px - sg.x) * ir; ny = (py - sg.y) * ir; nz = (pz - sg.z) * ir;
+        }
+        // scatter (wgsl:150-168)
+        float kk = (1.0f - RT_LOCAL_REFLECTANCE) * refl;
+        if (checker) {
+          const float fx = __builtin_floorf(4.0f * nx);
+          const float fy = __builtin_floorf(4.0f * ny + 0.5f);
+          const float h = (fx + fy) * 0.5f;
+          kk = (h == __builtin_floorf(h)) ? refl : 0.0f;
+        }
+        colx = colx + sc.x * kk; coly = coly + sc.y * kk; colz = colz + sc.z * kk;
+        refl = refl * RT_LOCAL_REFLECTANCE;
+        ox = px; oy = py; oz = pz;
+        depth++;
+        if ((hit & 1) == 0) {
+          // reflection (wgsl:170-172): dir - 2*dot(dir, n)*n
+          if (COUNT) c_Sm++;
+          if (STRICT) {
+            const float k2 = 2.0f * dot_strict(dx, dy, dz, nx, ny, nz);
+            dx = dx - k2 * nx; dy = dy - k2 * ny; dz = dz - k2 * nz;
+          } else {
+            const float k2 = -2.0f * dot_fast(dx, dy, dz, nx, ny, nz);
+            dx = __builtin_fmaf(k2, nx, dx); dy = __builtin_fmaf(k2, ny, dy); dz = __builtin_fmaf(k2, nz, dz);
+          }
+          state = depth > (uint32_t)RT_MAX_RAY_DEPTH ? ST_PATH_DONE : ST_READY;
+        } else {
+          // normal + random_unit_vector(): the direction is drawn in [G]; park the normal in d
+          if (COUNT) c_Sd++;
+          dx = nx; dy = ny; dz = nz;
+          state = ST_NEED_DIR;
+        }
       }
     }
   }
-
-  // ---- write once ------------------------------------------------------------------------------
-  if (accum_f32) {
-    f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
-    reinterpret_cast<f32x4*>(a.accum)[pix] = o;
-  } else {
-    // acc* hold q/255 exactly; recover q
-    const uint32_t q = unorm8(acc0) | (unorm8(acc1) << 8) | (unorm8(acc2) << 16) | (unorm8(acc3) << 24);
-    reinterpret_cast<uint32_t*>(a.accum)[pix] = q;
-  }
-  if (a.rng_out) a.rng_out[pix] = rng;
 
   if (COUNT) {
     const uint32_t vals[12] = {c_T, c_D, c_H, c_R, c_M, c_S, c_Sm, c_J, c_Sd, c_N, c_P, c_rand};
 #pragma unroll
     for (int i = 0; i < 12; ++i) atomicAdd(&a.counters[i], (unsigned long long)vals[i]);
+    if (lane == 0) {
+      atomicAdd(&a.counters[12], 64ull * c_wt);
+      atomicAdd(&a.counters[13], 64ull * c_wr);
+    }
   }
 }
 
@@ -353,9 +448,9 @@ __global__ void rt_quantize_kernel(const f32x4* __restrict__ src, uint32_t* __re
 
 }  // namespace
 
-hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t my_tiles, bool strict, bool count, hipStream_t stream) {
-  if (my_tiles == 0) return hipSuccess;
-  const dim3 grid(my_tiles), block(64);
+hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, hipStream_t stream) {
+  if (n_waves == 0 || a.my_tiles == 0) return hipSuccess;
+  const dim3 grid(n_waves), block(64);
   if (strict) {
     if (count) hipLaunchKernelGGL((rt_path_kernel<true, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rt_path_kernel<true, false>), grid, block, 0, stream, a);

@@ -129,6 +129,11 @@ class Raytracer:
         check(self._lib.rt_get_counters(self._h, C.byref(c)))
         return c.as_dict()
 
+    def occupancy(self):
+        c = _abi.RtCounters()
+        check(self._lib.rt_get_counters(self._h, C.byref(c)))
+        return c.occupancy()
+
     def accum_device_ptr(self):
         p, n = C.c_void_p(), C.c_size_t()
         check(self._lib.rt_accum_device_ptr(self._h, C.byref(p), C.byref(n)))

@@ -56,7 +56,7 @@ def test_pod_layouts():
     assert R.SPHERE_DTYPE.itemsize == 32 and R.MATERIAL_DTYPE.itemsize == 32 and R.CAMERA_DTYPE.itemsize == 160
     f = R.CAMERA_DTYPE.fields
     assert (f["pixel_to_world"][1], f["pos"][1], f["samples_per_pixel"][1], f["frames_to_render"][1], f["current_frame"][1]) == (64, 128, 148, 152, 156)
-    assert C.sizeof(R._abi.RtCounters) == 96
+    assert C.sizeof(R._abi.RtCounters) == 112
 
 
 def test_no_device_is_an_error_not_a_fallback():

@@ -1,0 +1,18 @@
+#!/bin/bash
+# rocprofv3 passes over the bench command. Usage: tools/prof.sh <tag> [bench args...]
+set -o pipefail
+tag=$1; shift
+out=gpurun_out/prof_$tag
+mkdir -p $out
+export TMPDIR=/tmp
+cmd="bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras $*"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $cmd > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
+for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS" \
+            "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
+            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  timeout -s KILL 300 rocprofv3 --pmc $pass --output-format csv -d $out/pmc_$name -- python3 $cmd > $out/pmc_$name.log 2>&1 || { echo "pass $name failed"; tail -3 $out/pmc_$name.log; }
+done
+python3 tools/prof_summary.py $out > $out/summary.txt 2>&1
+cat $out/summary.txt
