@@ -53,7 +53,7 @@ def parse():
     return p.parse_args()
 
 
-def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, device):
+def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, device, use_dist):
     """Times `steps` compute passes. Returns dict(seconds, kernel_ms, launches, flops_per_launch, samples)."""
     from raytracer_amd import dist as rdist
     from raytracer_amd import host
@@ -62,7 +62,7 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
     frames_total = warmup + steps + 4
     rt = R.Raytracer(W, H, flags, device=device)
     rt.set_scene(cfg["spheres"], cfg["materials"])
-    img = rdist.DeviceImage(rt, f"cuda:{device}") if world > 1 else None
+    img = rdist.DeviceImage(rt, f"cuda:{device}") if use_dist else None
     if split == "tiles":
         rt.set_partition(rank, world)
     tb = host.time_table(frames_total * (world if split == "frames" else 1))
@@ -92,21 +92,23 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
     rt.sync()
     rt.enable_timing(True)
     rt.timing_reset()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(warmup, warmup + steps):
         step(i)
     rt.sync()
-    if world > 1:
+    if use_dist:
         rdist.combine_sum(img.tensor, dst=0)  # ONE RCCL reduce per render
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     seconds = time.perf_counter() - t0
     kernel_ms, launches = rt.timing()
     info = rt.device_info()
+    if img is not None:
+        rt.bind_accum(0, 0)
     rt.close()
     cov_w = W if flags & R.RT_DISPATCH_FULL else (W // 16) * 16
     cov_h = H if flags & R.RT_DISPATCH_FULL else (H // 16) * 16
@@ -133,12 +135,19 @@ def cpu_baseline(cfg, flags, target_seconds):
         O.compute(img, cfg["spheres"], cfg["materials"], cam, int(tb[0]), rank=0, world=world, threads=threads)
         return time.perf_counter() - t0, img.counters_dict()
 
-    probe_world = 4096
-    dt, c = run(probe_world)
-    rate = c["N"] / max(dt, 1e-6)
+    # calibrate on growing tile samples until one takes >= 0.5 s, then size the timed sample
     total = (W // 16) * 16 * (H // 16) * 16 * spp
-    world = int(max(1, min(probe_world, round(total / max(rate * target_seconds, 1.0)))))
-    dt, c = run(world)
+    world = 4096
+    while True:
+        dt, c = run(world)
+        if dt >= 0.5 or world == 1:
+            break
+        world = max(1, world // 8)
+    rate = c["N"] / max(dt, 1e-6)
+    want = int(max(1, min(4096, round(total / max(rate * target_seconds, 1.0)))))
+    if want != world:
+        world = want
+        dt, c = run(world)
     return {"value": c["N"] / dt, "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": f"one frame, every {world}-th 8x8 tile of the {W}x{H} image at {spp} spp "
                       f"({c['N']} samples, {c['R']} rays, {dt:.1f} s), oracle/rt_oracle.c with OpenMP",
@@ -161,9 +170,12 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1 runs the N > 1 code path (torch-owned image, RCCL reduce) with one rank
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     import raytracer_amd as R
     from raytracer_amd import configs
@@ -177,7 +189,7 @@ def main():
 
     def run(math):
         flags = base_flags | (R.RT_MATH_FAST if math == "fast" else R.RT_MATH_STRICT)
-        m = measure(R, cfg, flags, rank, world, args.steps, args.warmup, args.split, dist, torch, local_rank)
+        m = measure(R, cfg, flags, rank, world, args.steps, args.warmup, args.split, dist, torch, local_rank, use_dist)
         sec = torch.tensor([m["seconds"]], dtype=torch.float64, device=f"cuda:{local_rank}")
         if world > 1:
             dist.all_reduce(sec, op=dist.ReduceOp.MAX)
@@ -234,7 +246,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, base_flags, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

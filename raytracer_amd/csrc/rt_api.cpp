@@ -46,6 +46,7 @@ struct rt_ctx {
   int compute_units = 0;
   int waves_per_cu = 0;       // launch width override (0 = default); env RT_WAVES_PER_CU
   int reject_tries = 0;       // rejection rounds override (0 = default); env RT_REJECT_TRIES
+  int batch_lanes = 0;        // parked-lane batch override (0 = default); env RT_BATCH_LANES
   bool counting = false;
   rt_f32x4 *sph_test = nullptr, *sph_shade = nullptr, *sph_col = nullptr;
   uint32_t n_spheres = 0;
@@ -54,8 +55,8 @@ struct rt_ctx {
   uint32_t time_bits = 0;
   uint32_t rank = 0, world = 1;
   // time table for batched launches: pinned staging + device copy, guarded by an event
-  uint32_t* time_host = nullptr;
-  uint32_t* time_dev = nullptr;
+  uint2* time_host = nullptr;
+  uint2* time_dev = nullptr;
   size_t time_cap = 0;
   hipEvent_t time_copied = nullptr;
   bool time_pending = false;
@@ -86,7 +87,13 @@ void covered(const rt_ctx* c, uint32_t* cov_w, uint32_t* cov_h) {
   }
 }
 
-int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_bits0, const uint32_t* time_table_dev) {
+float frame_cw(uint32_t frame) {
+  // combine_pixel_cache_color (wgsl:107-109): cw = f32(frame) / f32(frame + 1), one IEEE division
+  const volatile float f = (float)frame, n = (float)(frame + 1u);
+  return f / n;
+}
+
+int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_bits0, const uint2* time_table_dev) {
   rt_kargs a{};
   std::memcpy(a.p2w, ctx->camera.pixel_to_world, sizeof a.p2w);
   a.pos[0] = ctx->camera.pos[0];
@@ -103,7 +110,10 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.first_frame = first_frame;
   a.n_frames = n_frames;
   a.time_bits0 = time_bits0;
-  a.time_table = time_table_dev;
+  a.cw0 = frame_cw(first_frame);
+  a.frame_table = time_table_dev;
+  a.inv_spp = (a.spp & (a.spp - 1u)) == 0u ? 1.0f / (float)a.spp : 0.0f;
+  a.batch_lanes = ctx->batch_lanes > 0 ? (uint32_t)ctx->batch_lanes : 1u;
   a.n_spheres = ctx->n_spheres;
   a.flags = ctx->flags;
   a.sph_test = ctx->sph_test;
@@ -187,6 +197,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   c->compute_units = prop.multiProcessorCount;
   if (const char* e1 = std::getenv("RT_WAVES_PER_CU")) c->waves_per_cu = std::atoi(e1);   // tuning knobs for experiments
   if (const char* e2 = std::getenv("RT_REJECT_TRIES")) c->reject_tries = std::atoi(e2);
+  if (const char* e3 = std::getenv("RT_BATCH_LANES")) c->batch_lanes = std::atoi(e3);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
   if (e == hipSuccess) {
     c->stream = c->own_stream;
@@ -315,12 +326,17 @@ int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames) 
       ctx->time_cap = 0;
       size_t cap = 256;
       while (cap < live) cap *= 2;
-      RT_HIP(hipMalloc((void**)&ctx->time_dev, cap * sizeof(uint32_t)));
-      RT_HIP(hipHostMalloc((void**)&ctx->time_host, cap * sizeof(uint32_t), hipHostMallocDefault));
+      RT_HIP(hipMalloc((void**)&ctx->time_dev, cap * sizeof(uint2)));
+      RT_HIP(hipHostMalloc((void**)&ctx->time_host, cap * sizeof(uint2), hipHostMallocDefault));
       ctx->time_cap = cap;
     }
-    std::memcpy(ctx->time_host, time_bits, live * sizeof(uint32_t));
-    RT_HIP(hipMemcpyAsync(ctx->time_dev, ctx->time_host, live * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    for (uint32_t i = 0; i < live; ++i) {
+      const float cw = frame_cw(cur + i);
+      uint32_t cw_bits;
+      std::memcpy(&cw_bits, &cw, 4);
+      ctx->time_host[i] = make_uint2(time_bits[i], cw_bits);
+    }
+    RT_HIP(hipMemcpyAsync(ctx->time_dev, ctx->time_host, live * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(hipEventRecord(ctx->time_copied, ctx->stream));
     ctx->time_pending = true;
     rc = launch(ctx, cur, live, time_bits[0], ctx->time_dev);

@@ -21,8 +21,11 @@ struct rt_kargs {
   uint32_t reject_tries;    // rejection-sampling rounds per loop iteration (>= 1)
   uint32_t spp;
   uint32_t first_frame, n_frames;
-  uint32_t time_bits0;           // time bits of the first frame
-  const uint32_t* time_table;    // n_frames entries when n_frames > 1 (device), else may be null
+  uint32_t time_bits0;           // time bits of the first frame (single-frame launches)
+  float cw0;                     // f32(first_frame) / f32(first_frame + 1) (single-frame launches)
+  const uint2* frame_table;      // n_frames x {time bits, bits of cw} when n_frames > 1 (device), else null
+  float inv_spp;                 // 1/spp when spp is a power of two (exact), else 0
+  uint32_t batch_lanes;          // lanes that must be parked before frame ends / pixel hand-outs are serviced
   uint32_t n_spheres;
   uint32_t flags;
   const rt_f32x4* sph_test;

@@ -78,7 +78,14 @@ __device__ __forceinline__ uint32_t unorm8(float x) {  // rgba8unorm store: clam
   return (uint32_t)__builtin_rintf(c * 255.0f);
 }
 
-enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_READY = 2, ST_NEED_DIR = 3, ST_NEW_RAY = 4, ST_PATH_DONE = 5, ST_GOT_DIR = 6 };
+// rgba8unorm load, q / 255 (q <= 255): fma(q, c, RN(q * c_lo)) with c = f32(1/255), c_lo = f32(1/255 - c)
+// equals the correctly rounded quotient for all 256 inputs (checked exhaustively in tests/test_host.py)
+__device__ __forceinline__ float unorm8_to_f32(uint32_t q) {
+  const float f = (float)q;
+  return __builtin_fmaf(f, 0x1.010102p-8f, f * -0x1.fdfdfep-33f);
+}
+
+enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_READY = 2, ST_NEED_DIR = 3, ST_NEW_RAY = 4, ST_PATH_DONE = 5, ST_GOT_DIR = 6, ST_FRAME_END = 7 };
 
 template <bool STRICT, bool COUNT>
 __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
@@ -101,7 +108,8 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
 
   // per-lane state machine:
   //   NEED_PIXEL -[A]-> NEW_RAY -[G]-> READY -[C]-> PATH_DONE (miss / depth) | READY (mirror) | NEED_DIR (diffuse)
-  //   NEED_DIR -[G]-> GOT_DIR -> READY | PATH_DONE ;  PATH_DONE -[E]-> NEW_RAY | NEED_PIXEL ;  NEED_PIXEL -[A]-> DEAD when the queue is empty
+  //   NEED_DIR -[G]-> GOT_DIR -> READY | PATH_DONE ;  PATH_DONE -[E]-> NEW_RAY | FRAME_END ;  FRAME_END -[F]-> NEW_RAY | NEED_PIXEL ;
+  //   NEED_PIXEL -[A]-> DEAD when the queue is empty
   uint32_t state = ST_NEED_PIXEL;
   uint32_t u = 0, v = 0;
   float pcx = 0, pcy = 0, pcz = 0, pdx = 0, pdy = 0, pdz = 0;  // pixel_center, pixel_delta
@@ -113,53 +121,68 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
   float gqx = 0, gqy = 0, gqz = 0, gl2 = 1.0f;                 // accepted point of random_in_unit_sphere, |q|^2
 
   for (;;) {
-    // ================= [E] path end: next sample / next frame / next pixel =================
+    // ================= [E] path end: next sample (cheap, every lane that finished a path) =================
     if (state == ST_PATH_DONE) {
       // send_rays: color += ray_color(ray) (wgsl:120)
       sumx = sumx + colx; sumy = sumy + coly; sumz = sumz + colz;
       sample++;
-      state = ST_NEW_RAY;
-      if (sample == a.spp) {
-        // ---- end of this pixel's frame: color / spp (wgsl:122), store_color (wgsl:96-112) ----
-        const float p0 = sumx / spp_f, p1 = sumy / spp_f, p2 = sumz / spp_f, p3 = 1.0f;
-        if (COUNT) c_P++;
-        if (combine_sum) {
-          acc0 = acc0 + p0; acc1 = acc1 + p1; acc2 = acc2 + p2; acc3 = acc3 + p3;
+      state = sample == a.spp ? ST_FRAME_END : ST_NEW_RAY;
+    }
+
+    // ================= [F] frame end + [A] pixel hand-out, batched =================
+    // Both are rare per lane (once per spp samples) but, with 64 desynchronised lanes, would run at
+    // 1/64 occupancy in every other iteration. Lanes park in FRAME_END / NEED_PIXEL until `batch_lanes`
+    // of them wait, or nothing else is runnable in the wave.
+    const unsigned long long parked = __ballot(state == ST_FRAME_END || state == ST_NEED_PIXEL);
+    const unsigned long long runnable = __ballot(state != ST_FRAME_END && state != ST_NEED_PIXEL && state != ST_DEAD);
+    const bool service = parked && ((uint32_t)__popcll(parked) >= a.batch_lanes || !runnable);
+    if (service && state == ST_FRAME_END) {
+      // ---- end of this pixel's frame: color / spp (wgsl:122), store_color (wgsl:96-112) ----
+      float p0, p1, p2;
+      if (a.inv_spp > 0.0f) {  // spp is a power of two: x / spp == x * (1/spp) exactly
+        p0 = sumx * a.inv_spp; p1 = sumy * a.inv_spp; p2 = sumz * a.inv_spp;
+      } else {
+        p0 = sumx / spp_f; p1 = sumy / spp_f; p2 = sumz / spp_f;
+      }
+      const float p3 = 1.0f;
+      if (COUNT) c_P++;
+      if (combine_sum) {
+        acc0 = acc0 + p0; acc1 = acc1 + p1; acc2 = acc2 + p2; acc3 = acc3 + p3;
+      } else {
+        // cw = f32(frame) / f32(frame + 1) (wgsl:108-109), computed on the host with the same IEEE division
+        const float cw = a.frame_table ? as_f32(a.frame_table[k].y) : a.cw0;
+        const float rw = 1.0f - cw;
+        acc0 = p0 * rw + acc0 * cw; acc1 = p1 * rw + acc1 * cw; acc2 = p2 * rw + acc2 * cw; acc3 = p3 * rw + acc3 * cw;
+      }
+      uint32_t q8 = 0;
+      if (!accum_f32) {  // the reference re-quantises to rgba8unorm every frame (raytracing.rs:30,47)
+        const uint32_t q0 = unorm8(acc0), q1 = unorm8(acc1), q2 = unorm8(acc2), q3 = unorm8(acc3);
+        q8 = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+        acc0 = unorm8_to_f32(q0); acc1 = unorm8_to_f32(q1); acc2 = unorm8_to_f32(q2); acc3 = unorm8_to_f32(q3);
+      }
+      k++;
+      if (k == a.n_frames) {
+        // ---- pixel finished: write once, then ask for the next pixel ----
+        const size_t pix = (size_t)v * a.width + u;
+        if (accum_f32) {
+          f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
+          reinterpret_cast<f32x4*>(a.accum)[pix] = o;
         } else {
-          const uint32_t frame = a.first_frame + k;
-          const float cw = (float)frame / (float)(frame + 1u);
-          const float rw = 1.0f - cw;
-          acc0 = p0 * rw + acc0 * cw; acc1 = p1 * rw + acc1 * cw; acc2 = p2 * rw + acc2 * cw; acc3 = p3 * rw + acc3 * cw;
+          reinterpret_cast<uint32_t*>(a.accum)[pix] = q8;
         }
-        uint32_t q8 = 0;
-        if (!accum_f32) {  // the reference re-quantises to rgba8unorm every frame (raytracing.rs:30,47)
-          const uint32_t q0 = unorm8(acc0), q1 = unorm8(acc1), q2 = unorm8(acc2), q3 = unorm8(acc3);
-          q8 = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
-          acc0 = (float)q0 / 255.0f; acc1 = (float)q1 / 255.0f; acc2 = (float)q2 / 255.0f; acc3 = (float)q3 / 255.0f;
-        }
-        k++;
-        if (k == a.n_frames) {
-          // ---- pixel finished: write once, then ask for the next pixel ----
-          const size_t pix = (size_t)v * a.width + u;
-          if (accum_f32) {
-            f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
-            reinterpret_cast<f32x4*>(a.accum)[pix] = o;
-          } else {
-            reinterpret_cast<uint32_t*>(a.accum)[pix] = q8;
-          }
-          if (a.rng_out) a.rng_out[pix] = rng;
-          state = ST_NEED_PIXEL;
-        } else {
-          rng = rng_seed(u, v, a.time_table[k]);
-          rng = rng_step(rng);
-          if (COUNT) c_rand++;
-          sample = 0; sumx = sumy = sumz = 0.0f;
-        }
+        if (a.rng_out) a.rng_out[pix] = rng;
+        state = ST_NEED_PIXEL;
+      } else {
+        rng = rng_seed(u, v, a.frame_table[k].x);
+        rng = rng_step(rng);
+        if (COUNT) c_rand++;
+        sample = 0; sumx = sumy = sumz = 0.0f;
+        state = ST_NEW_RAY;
       }
     }
 
     // ================= [A] hand out pixels =================
-    const unsigned long long need = __ballot(state == ST_NEED_PIXEL);
+    const unsigned long long need = service ? __ballot(state == ST_NEED_PIXEL) : 0ull;
     if (need) {
       const uint32_t n_need = (uint32_t)__popcll(need);
       const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -208,11 +231,11 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
               acc0 = c.x; acc1 = c.y; acc2 = c.z; acc3 = c.w;
             } else {
               const uint32_t q = reinterpret_cast<const uint32_t*>(a.accum)[pix];
-              acc0 = (float)(q & 255u) / 255.0f; acc1 = (float)((q >> 8) & 255u) / 255.0f;
-              acc2 = (float)((q >> 16) & 255u) / 255.0f; acc3 = (float)(q >> 24) / 255.0f;
+              acc0 = unorm8_to_f32(q & 255u); acc1 = unorm8_to_f32((q >> 8) & 255u);
+              acc2 = unorm8_to_f32((q >> 16) & 255u); acc3 = unorm8_to_f32(q >> 24);
             }
             k = 0;
-            rng = rng_seed(u, v, a.time_table ? a.time_table[0] : a.time_bits0);
+            rng = rng_seed(u, v, a.frame_table ? a.frame_table[0].x : a.time_bits0);
             rng = rng_step(rng);  // initialize_rng's discarded rand() (wgsl:262)
             if (COUNT) c_rand++;
             sample = 0; sumx = sumy = sumz = 0.0f;

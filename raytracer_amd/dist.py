@@ -37,7 +37,7 @@ def combine_sum(image, dst=0, group=None):
     """Sum-reduce the per-GPU accumulation images onto rank `dst` (RCCL reduce over xGMI, or gloo on
     CPU). `image` is a torch tensor: float32 H x W x 4, or uint8 H x W x 4 for RGBA8 tile images, which
     are reduced as int32 words (tiles are disjoint, so a sum is a merge)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return image
     buf = image.view(torch.int32) if image.dtype == torch.uint8 else image
     dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM, group=group)

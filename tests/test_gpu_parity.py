@@ -232,3 +232,44 @@ def test_errors_are_codes_not_crashes():
     with pytest.raises(R.RtError):
         rt.set_camera(cam)
     rt.close()
+
+
+def test_torch_owned_image_and_single_rank_rccl_reduce():
+    """rt_bind_accum: the kernel accumulates into a torch tensor, and that same tensor goes through a
+    (1-rank) RCCL reduce — the memory path bench.py --gpus N uses."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    R = _rt()
+    from raytracer_amd import dist as rdist
+
+    W, H, spp, frames = 64, 48, 2, 3
+    flags = O.ACCUM_F32
+    spheres, mats = scenes.default_scene(1)
+    cam = scenes.camera_raw(W, H, spp=spp, frames=frames)
+    rt = R.Raytracer(W, H, flags)
+    rt.set_scene(spheres, mats)
+    img = rdist.DeviceImage(rt, "cuda:0")
+    rt.set_camera(cam)
+    rt.render_frames(O.time_bits_table(frames))
+    rt.sync()
+    started = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        started = True
+    try:
+        rdist.combine_sum(img.tensor, dst=0)
+        torch.cuda.synchronize()
+    finally:
+        if started:
+            dist.destroy_process_group()
+    ref = O.OracleImage(W, H, flags)
+    O.render(ref, spheres, mats, cam, 0, frames)
+    assert np.array_equal(img.tensor.cpu().numpy().view(np.uint32), ref.accum.view(np.uint32))
+    assert np.array_equal(rt.read_accum_f32().view(np.uint32), ref.accum.view(np.uint32))
+    rt.bind_accum(0, 0)  # back to the context's own image before the tensor dies
+    rt.close()

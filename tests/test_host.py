@@ -81,3 +81,20 @@ def test_png_writer_round_trip(tmp_path):
     lin = (img[..., :3] / 255.0) ** 2.2
     srgb = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * lin ** (1 / 2.4) - 0.055)
     assert np.abs(shown - np.rint(srgb * 255)).max() <= 1
+
+
+def test_unorm8_load_formula_is_exact_for_all_256_values():
+    """The kernel's rgba8unorm load, fma(q, c, RN(q * c_lo)) with c = f32(1/255), c_lo = f32(1/255 - c)
+    (rt_kernels.hip unorm8_to_f32), equals the correctly rounded q / 255 for every q; the constants in
+    the source are these."""
+    import re, os
+
+    c = np.float32(1) / np.float32(255)
+    c_lo = np.float32(1 / 255 - float(c))
+    q = np.arange(256, dtype=np.float32)
+    t = (q * c_lo).astype(np.float64)  # RN_f32(q * c_lo)
+    fma = (q.astype(np.float64) * float(c) + t).astype(np.float32)  # exact product and sum in f64, one rounding
+    assert np.array_equal(fma, q / np.float32(255))
+    src = open(os.path.join(os.path.dirname(__file__), "..", "raytracer_amd", "csrc", "rt_kernels.hip")).read()
+    m = re.search(r"__builtin_fmaf\(f, (\S+)f, f \* (\S+)f\)", src)
+    assert float.fromhex(m.group(1)) == float(c) and float.fromhex(m.group(2)) == float(c_lo)
