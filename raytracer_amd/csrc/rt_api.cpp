@@ -109,7 +109,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.spp = ctx->camera.samples_per_pixel;
   a.first_frame = first_frame;
   a.n_frames = n_frames;
-  a.time_bits0 = time_bits0;
+  a.seed_t0 = time_bits0 * 87189u + 189273u;
   a.cw0 = frame_cw(first_frame);
   a.frame_table = time_table_dev;
   a.inv_spp = (a.spp & (a.spp - 1u)) == 0u ? 1.0f / (float)a.spp : 0.0f;
@@ -334,7 +334,7 @@ int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames) 
       const float cw = frame_cw(cur + i);
       uint32_t cw_bits;
       std::memcpy(&cw_bits, &cw, 4);
-      ctx->time_host[i] = make_uint2(time_bits[i], cw_bits);
+      ctx->time_host[i] = make_uint2(time_bits[i] * 87189u + 189273u, cw_bits);
     }
     RT_HIP(hipMemcpyAsync(ctx->time_dev, ctx->time_host, live * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(hipEventRecord(ctx->time_copied, ctx->stream));

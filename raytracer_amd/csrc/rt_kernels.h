@@ -21,9 +21,9 @@ struct rt_kargs {
   uint32_t reject_tries;    // rejection-sampling rounds per loop iteration (>= 1)
   uint32_t spp;
   uint32_t first_frame, n_frames;
-  uint32_t time_bits0;           // time bits of the first frame (single-frame launches)
+  uint32_t seed_t0;              // bits(time) * 87189 + 189273 of the first frame (single-frame launches; wgsl:260)
   float cw0;                     // f32(first_frame) / f32(first_frame + 1) (single-frame launches)
-  const uint2* frame_table;      // n_frames x {time bits, bits of cw} when n_frames > 1 (device), else null
+  const uint2* frame_table;      // n_frames x {seed_t, bits of cw} when n_frames > 1 (device), else null
   float inv_spp;                 // 1/spp when spp is a power of two (exact), else 0
   uint32_t batch_lanes;          // lanes that must be parked before frame ends / pixel hand-outs are serviced
   uint32_t n_spheres;

@@ -57,12 +57,12 @@ __device__ __forceinline__ float rng_unit(uint32_t rng) { return as_f32((rng & 0
     if (COUNT) c_rand++;    \
   } while (0)
 
-// raytrace_kernal.wgsl:255-261
-__device__ __forceinline__ uint32_t rng_seed(uint32_t u, uint32_t v, uint32_t time_bits) {
+// raytrace_kernal.wgsl:255-261: rng = x ^ y ^ t. The pixel part x ^ y is staged per tile; the frame
+// part t = bitcast<u32>(time) * 87189 + 189273 is computed on the host (same wrapping u32 arithmetic).
+__device__ __forceinline__ uint32_t rng_seed_pixel(uint32_t u, uint32_t v) {
   uint32_t x = (u << 15) ^ (u * 1729u + 8192374u);
   uint32_t y = (v << 21) ^ (v * 271u + 719827371u);
-  uint32_t t = time_bits * 87189u + 189273u;
-  return x ^ y ^ t;
+  return x ^ y;
 }
 
 // strict dot: (ax*bx + ay*by) + az*bz, three roundings for the products, two for the sums
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
   const const_f32x4_ptr sph_test = (const_f32x4_ptr)(uintptr_t)a.sph_test;
   const uint32_t n_spheres = a.n_spheres;
   const float spp_f = (float)a.spp;
+  __shared__ f32x4 tile_lds[128];  // per wave: 64 pixel records {pixel_center, v<<16|u} {pixel_delta, seed x^y}
 
   uint32_t c_T = 0, c_D = 0, c_H = 0, c_R = 0, c_M = 0, c_S = 0, c_Sm = 0, c_J = 0, c_Sd = 0, c_N = 0, c_P = 0, c_rand = 0;
   uint32_t c_wt = 0, c_wr = 0;  // wave-level iteration counts (diagnostics)
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
   //   NEED_DIR -[G]-> GOT_DIR -> READY | PATH_DONE ;  PATH_DONE -[E]-> NEW_RAY | FRAME_END ;  FRAME_END -[F]-> NEW_RAY | NEED_PIXEL ;
   //   NEED_PIXEL -[A]-> DEAD when the queue is empty
   uint32_t state = ST_NEED_PIXEL;
-  uint32_t u = 0, v = 0;
+  size_t pix = 0;            // pixel index v * width + u
+  uint32_t seed_xy = 0;      // pixel part of the RNG seed
   float pcx = 0, pcy = 0, pcz = 0, pdx = 0, pdy = 0, pdz = 0;  // pixel_center, pixel_delta
   float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;                // accumulation pixel
   uint32_t k = 0, rng = 0, sample = 0, depth = 0;
@@ -163,7 +165,6 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
       k++;
       if (k == a.n_frames) {
         // ---- pixel finished: write once, then ask for the next pixel ----
-        const size_t pix = (size_t)v * a.width + u;
         if (accum_f32) {
           f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
           reinterpret_cast<f32x4*>(a.accum)[pix] = o;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
         if (a.rng_out) a.rng_out[pix] = rng;
         state = ST_NEED_PIXEL;
       } else {
-        rng = rng_seed(u, v, a.frame_table[k].x);
+        rng = seed_xy ^ a.frame_table[k].x;
         rng = rng_step(rng);
         if (COUNT) c_rand++;
         sample = 0; sumx = sumy = sumz = 0.0f;
@@ -187,8 +188,14 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
       const uint32_t n_need = (uint32_t)__popcll(need);
       const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
       const uint32_t avail = q_end - q_cur;
-      uint32_t slot = q_cur + my;
-      bool got = my < avail;
+      const bool wants = state == ST_NEED_PIXEL;
+      bool got = false;
+      f32x4 rec0 = {0, 0, 0, 0}, rec1 = {0, 0, 0, 0};
+      if (wants && my < avail) {  // a pixel of the tile already staged in LDS
+        const uint32_t w = (q_cur + my) & 63u;
+        rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
+        got = true;
+      }
       if (n_need > avail) {
         uint32_t base = 0xffffffffu;
         if (more) {
@@ -197,7 +204,33 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
           if (base >= a.my_tiles) { more = false; base = 0xffffffffu; }
         }
         if (base != 0xffffffffu) {
-          if (!got) { slot = base * 64u + (my - avail); got = true; }
+          // ---- stage tile `base`: all 64 lanes compute the per-pixel constants of its 64 pixels at full
+          // occupancy (pixel_to_world, get_pixel_delta wgsl:85-94; the pixel part of the RNG seed
+          // wgsl:258-259) into LDS; lanes pick their record up when they are handed the pixel.
+          const uint32_t tile = base * a.world + a.rank;
+          const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+          const uint32_t pu = tx * 8u + (lane & 7u), pv = ty * 8u + (lane >> 3);
+          const float vx = (float)pu, vy = (float)(a.height - pv);
+          const float wx = (float)(pu + 1u), wy = (float)(a.height - (pv + 1u));
+          const float cx = ((m[0] * vx + m[4] * vy) + m[8] * 0.0f) + m[12] * 1.0f;
+          const float cy = ((m[1] * vx + m[5] * vy) + m[9] * 0.0f) + m[13] * 1.0f;
+          const float cz = ((m[2] * vx + m[6] * vy) + m[10] * 0.0f) + m[14] * 1.0f;
+          const float nx = ((m[0] * wx + m[4] * wy) + m[8] * 0.0f) + m[12] * 1.0f;
+          const float ny = ((m[1] * wx + m[5] * wy) + m[9] * 0.0f) + m[13] * 1.0f;
+          const float nz = ((m[2] * wx + m[6] * wy) + m[10] * 0.0f) + m[14] * 1.0f;
+          const bool inside = pu < a.cov_w && pv < a.cov_h;  // false only on ragged edges in RT_DISPATCH_FULL
+          f32x4 w0, w1;
+          w0.x = cx; w0.y = cy; w0.z = cz; w0.w = as_f32(inside ? (pv << 16 | pu) : 0xffffffffu);
+          w1.x = nx - cx; w1.y = ny - cy; w1.z = nz - cz; w1.w = as_f32(rng_seed_pixel(pu, pv));
+          __builtin_amdgcn_wave_barrier();  // the reads of the old tile above stay before these writes
+          tile_lds[lane * 2u] = w0; tile_lds[lane * 2u + 1u] = w1;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (wants && !got) {
+            const uint32_t w = my - avail;
+            rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
+            got = true;
+          }
           q_cur = base * 64u + (n_need - avail);
           q_end = base * 64u + 64u;
         } else {
@@ -206,41 +239,29 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
       } else {
         q_cur += n_need;
       }
-      if (state == ST_NEED_PIXEL) {
+      if (wants) {
         if (!got) {
           state = ST_DEAD;
-        } else {
-          const uint32_t tile = (slot >> 6) * a.world + a.rank;
-          const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-          u = tx * 8u + (slot & 7u);
-          v = ty * 8u + ((slot >> 3) & 7u);
-          if (u < a.cov_w && v < a.cov_h) {  // false only on ragged edges in RT_DISPATCH_FULL: take another slot next round
-            // pixel_to_world / get_pixel_delta (wgsl:85-94)
-            const float vx = (float)u, vy = (float)(a.height - v);
-            const float wx = (float)(u + 1u), wy = (float)(a.height - (v + 1u));
-            pcx = ((m[0] * vx + m[4] * vy) + m[8] * 0.0f) + m[12] * 1.0f;
-            pcy = ((m[1] * vx + m[5] * vy) + m[9] * 0.0f) + m[13] * 1.0f;
-            pcz = ((m[2] * vx + m[6] * vy) + m[10] * 0.0f) + m[14] * 1.0f;
-            const float nx = ((m[0] * wx + m[4] * wy) + m[8] * 0.0f) + m[12] * 1.0f;
-            const float ny = ((m[1] * wx + m[5] * wy) + m[9] * 0.0f) + m[13] * 1.0f;
-            const float nz = ((m[2] * wx + m[6] * wy) + m[10] * 0.0f) + m[14] * 1.0f;
-            pdx = nx - pcx; pdy = ny - pcy; pdz = nz - pcz;
-            const size_t pix = (size_t)v * a.width + u;
-            if (accum_f32) {
-              const f32x4 c = reinterpret_cast<const f32x4*>(a.accum)[pix];
-              acc0 = c.x; acc1 = c.y; acc2 = c.z; acc3 = c.w;
-            } else {
-              const uint32_t q = reinterpret_cast<const uint32_t*>(a.accum)[pix];
-              acc0 = unorm8_to_f32(q & 255u); acc1 = unorm8_to_f32((q >> 8) & 255u);
-              acc2 = unorm8_to_f32((q >> 16) & 255u); acc3 = unorm8_to_f32(q >> 24);
-            }
-            k = 0;
-            rng = rng_seed(u, v, a.frame_table ? a.frame_table[0].x : a.time_bits0);
-            rng = rng_step(rng);  // initialize_rng's discarded rand() (wgsl:262)
-            if (COUNT) c_rand++;
-            sample = 0; sumx = sumy = sumz = 0.0f;
-            state = ST_NEW_RAY;
+        } else if (as_u32(rec0.w) != 0xffffffffu) {  // else: outside the covered area, take another slot next round
+          pcx = rec0.x; pcy = rec0.y; pcz = rec0.z;
+          pdx = rec1.x; pdy = rec1.y; pdz = rec1.z;
+          const uint32_t uvp = as_u32(rec0.w);
+          pix = (size_t)(uvp >> 16) * a.width + (uvp & 0xffffu);
+          seed_xy = as_u32(rec1.w);
+          if (accum_f32) {
+            const f32x4 c = reinterpret_cast<const f32x4*>(a.accum)[pix];
+            acc0 = c.x; acc1 = c.y; acc2 = c.z; acc3 = c.w;
+          } else {
+            const uint32_t q = reinterpret_cast<const uint32_t*>(a.accum)[pix];
+            acc0 = unorm8_to_f32(q & 255u); acc1 = unorm8_to_f32((q >> 8) & 255u);
+            acc2 = unorm8_to_f32((q >> 16) & 255u); acc3 = unorm8_to_f32(q >> 24);
           }
+          k = 0;
+          rng = seed_xy ^ (a.frame_table ? a.frame_table[0].x : a.seed_t0);
+          rng = rng_step(rng);  // initialize_rng's discarded rand() (wgsl:262)
+          if (COUNT) c_rand++;
+          sample = 0; sumx = sumy = sumz = 0.0f;
+          state = ST_NEW_RAY;
         }
       }
     }
