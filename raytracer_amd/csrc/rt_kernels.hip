@@ -73,6 +73,42 @@ __device__ __forceinline__ float dot_fast(float ax, float ay, float az, float bx
   return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
 }
 
+// Correctly rounded f32 square root (== the oracle's sqrtf). For x >= 2^-96 (and +inf / NaN) this is
+// the compiler's own expansion without its denormal pre-scaling and class fix-up: v_sqrt_f32 is
+// within 1 ulp, and the two FMA residuals pick the correctly rounded neighbour. Smaller x (0,
+// denormals, negatives) takes the generic path.
+__device__ __forceinline__ float sqrt_rn(float x) {
+  if (__builtin_expect(x < 0x1p-96f, 0)) return __builtin_sqrtf(x);
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = as_f32(as_u32(s) - 1u), up = as_f32(as_u32(s) + 1u);
+  const float rd = __builtin_fmaf(-dn, s, x), ru = __builtin_fmaf(-up, s, x);
+  float r = rd <= 0.0f ? dn : s;
+  r = ru > 0.0f ? up : r;
+  return r;
+}
+
+// Correctly rounded f32 division by a divisor whose refined reciprocal is shared. This is the
+// compiler's v_div_scale / v_div_fmas / v_div_fixup expansion specialised to operands for which the
+// scale is 1 and no fix-up applies: |x|, |y| in [2^-60, 2^60]. rcp_refined(y) = r1 = r0 + r0*(1 - y*r0).
+struct rn_divisor { float y, r; bool nice; };
+__device__ __forceinline__ rn_divisor make_divisor(float y) {
+  rn_divisor d;
+  d.y = y;
+  const float ay = __builtin_fabsf(y);
+  d.nice = ay >= 0x1p-60f && ay <= 0x1p60f;
+  const float r0 = __builtin_amdgcn_rcpf(y);
+  d.r = __builtin_fmaf(__builtin_fmaf(-y, r0, 1.0f), r0, r0);
+  return d;
+}
+__device__ __forceinline__ float div_rn(float x, const rn_divisor& d) {
+  const float ax = __builtin_fabsf(x);
+  if (__builtin_expect(!(d.nice && ax >= 0x1p-60f && ax <= 0x1p60f), 0)) return x / d.y;
+  float q = x * d.r;
+  q = __builtin_fmaf(__builtin_fmaf(-d.y, q, x), d.r, q);
+  q = __builtin_fmaf(__builtin_fmaf(-d.y, q, x), d.r, q);
+  return q;
+}
+
 __device__ __forceinline__ uint32_t unorm8(float x) {  // rgba8unorm store: clamp (NaN -> 0), *255, RNE
   float c = __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f);
   return (uint32_t)__builtin_rintf(c * 255.0f);
@@ -320,8 +356,8 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
     if (state == ST_GOT_DIR) {
       // rec.normal + normalize(p) (wgsl:165,292-294), once per accepted lane after all rounds
       if (STRICT) {
-        const float len = __builtin_sqrtf(gl2);
-        dx = dx + gqx / len; dy = dy + gqy / len; dz = dz + gqz / len;
+        const rn_divisor len = make_divisor(sqrt_rn(gl2));
+        dx = dx + div_rn(gqx, len); dy = dy + div_rn(gqy, len); dz = dz + div_rn(gqz, len);
       } else {
         const float il = __builtin_amdgcn_rsqf(gl2);
         dx = __builtin_fmaf(gqx, il, dx); dy = __builtin_fmaf(gqy, il, dy); dz = __builtin_fmaf(gqz, il, dz);
@@ -336,9 +372,11 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
       int hit = -1;
       const float a_fast = dot_fast(dx, dy, dz, dx, dy, dz);
       float a_lit = a_fast, inv_a = 0.0f, a_margin = 0.0f;
+      rn_divisor a_div = {1.0f, 1.0f, false};
       if (STRICT) {
-        const float len = __builtin_sqrtf(dot_strict(dx, dy, dz, dx, dy, dz));
+        const float len = sqrt_rn(dot_strict(dx, dy, dz, dx, dy, dz));
         a_lit = len * len;  // length_squared (wgsl:306-309)
+        a_div = make_divisor(a_lit);
         a_margin = a_fast * 0x1p-18f;
       } else {
         inv_a = __builtin_amdgcn_rcpf(a_fast);
@@ -376,16 +414,16 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
           if (STRICT) {
             // hit_sphere (wgsl:200-231), literal
             const float hb = dot_strict(ocx, ocy, ocz, dx, dy, dz);
-            const float len = __builtin_sqrtf(dot_strict(ocx, ocy, ocz, ocx, ocy, ocz));
+            const float len = sqrt_rn(dot_strict(ocx, ocy, ocz, ocx, ocy, ocz));
             const float c = len * len - s.w;
             const float disc = hb * hb - a_lit * c;
             if (!(disc < 0.0f)) {
               if (COUNT) c_D++;
-              const float sq = __builtin_sqrtf(disc);
-              float root = (-hb - sq) / a_lit;
+              const float sq = sqrt_rn(disc);
+              float root = div_rn(-hb - sq, a_div);
               bool ok = true;
               if (root <= RT_RAY_TMIN || closest <= root) {
-                root = (-hb + sq) / a_lit;
+                root = div_rn(-hb + sq, a_div);
                 if (root <= RT_RAY_TMIN || closest <= root) ok = false;
               }
               if (ok) { closest = root; hit = (int)i; }
@@ -431,7 +469,8 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
             // exactly, barring overflow/underflow of a unit-length normal's components
             nx = ex * sc.w; ny = ey * sc.w; nz = ez * sc.w;
           } else {
-            nx = ex / sg.w; ny = ey / sg.w; nz = ez / sg.w;
+            const rn_divisor rd = make_divisor(sg.w);
+            nx = div_rn(ex, rd); ny = div_rn(ey, rd); nz = div_rn(ez, rd);
           }
         } else {
           px = __builtin_fmaf(closest, dx, ox); py = __builtin_fmaf(closest, dy, oy); pz = __builtin_fmaf(closest, dz, oz);
