@@ -202,11 +202,20 @@ def main():
         extras = run("fast" if args.math == "strict" else "strict")
 
     if rank == 0:
-        def roof(mm):
+        def traffic(math):
+            # HBM bytes per launch from the committed PMC pass of this same command (profiles/), or null
+            path = os.path.join(ROOT, "profiles", f"traffic_{args.config}_{math}.json")
+            try:
+                return json.load(open(path))["bytes_per_launch"] if world == 1 else None
+            except (OSError, ValueError, KeyError):
+                return None
+
+        def roof(mm, math=None):
             avg_ms = mm["kernel_ms"] / max(mm["launches"], 1)
             achieved = mm["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
             return {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4), "traffic": traffic(math or args.math),
+                    "traffic_algorithmic": cfg["width"] // 16 * 16 * (cfg["height"] // 16 * 16) * (32 if base_flags & R.RT_ACCUM_F32 else 8),
                     "kernel": "rt_path_kernel", "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_flops_per_launch": mm["flops_per_launch"],
                     "note": "FP32 vector roofline (no MFMA: no dense contraction); peak is the packed-FMA figure, "
@@ -236,10 +245,10 @@ def main():
             "roofline": roof(m),
             "device": m["device"],
         }
+        other = "fast" if args.math == "strict" else "strict"
         if extras is not None:
-            other = "fast" if args.math == "strict" else "strict"
             out[f"{other}_math"] = {"value": extras["samples_per_step"] * args.steps / extras["seconds"], "unit": "samples/s",
-                                    "ms_per_step": extras["seconds"] * 1e3 / args.steps, "roofline": roof(extras),
+                                    "ms_per_step": extras["seconds"] * 1e3 / args.steps, "roofline": roof(extras, other),
                                     "parity": "image within PSNR >= 40 dB of strict; RNG function bit-exact" if other == "fast"
                                     else "bit-identical to the oracle"}
         if world == 1 and not args.no_cpu_baseline:

@@ -73,6 +73,12 @@ int rt_read_rgba8(rt_ctx* ctx, void* dst, size_t bytes);
 /* The float4 accumulation image, W*H*16 bytes (RT_ACCUM_F32 contexts only). Synchronous. */
 int rt_read_accum_f32(rt_ctx* ctx, void* dst, size_t bytes);
 
+/* Checkpoint / resume (no counterpart in the reference, whose only persistent state is color_cache +
+ * current_frame + time): upload a previously read image in the context's own format (RGBA8: W*H*4
+ * bytes as read by rt_read_rgba8; F32: W*H*16 bytes as read by rt_read_accum_f32). Together with
+ * camera.current_frame and the time bits this resumes a render bit-identically. Synchronous. */
+int rt_write_image(rt_ctx* ctx, const void* src, size_t bytes);
+
 /* Test hook: final RNG state (u32) of every pixel after the most recent pass, W*H*4 bytes; pixels
  * no pass covered read 0. Recording is off until rt_enable_rng_capture(ctx, 1). Synchronous. */
 int rt_enable_rng_capture(rt_ctx* ctx, int enable);

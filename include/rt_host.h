@@ -20,6 +20,21 @@ typedef struct rth_app rth_app;
 int rth_camera_raw(uint32_t width, uint32_t height, const float pos[3], const float look[3], float fov, uint32_t spp,
                    uint32_t frames, uint32_t current_frame, rt_camera_raw* out);
 
+/* A stateful headless Camera (src/resources/camera.rs:23-36): the interactive controls without winit.
+ * rth_camera_key takes the reference's key names: "K"/"J" spp x2 / /2 and "I"/"U" frames x2 / /2, both
+ * clamped to [1,256]; "Backspace" -> 1/1; "ArrowUp"/"ArrowDown" zoom; "W","S","D","A","Space","ShiftLeft"
+ * move by `speed` = 0.05 along the view axes (camera.rs:133-175). Every handled input resets
+ * current_frame, as scene_was_updated does (camera.rs:283-288). */
+typedef struct rth_camera rth_camera;
+rth_camera* rth_camera_create(uint32_t width, uint32_t height);
+void rth_camera_destroy(rth_camera* cam);
+int rth_camera_key(rth_camera* cam, const char* key);
+int rth_camera_zoom(rth_camera* cam, float val);                              /* camera.rs:193-197 */
+int rth_camera_look_at_pixel(rth_camera* cam, float off_x, float off_y);      /* camera.rs:200-206 */
+int rth_camera_increase_frame(rth_camera* cam);                               /* camera.rs:252-265 */
+int rth_camera_render_finished(rth_camera* cam);                              /* camera.rs:279-281 */
+int rth_camera_get(rth_camera* cam, rt_camera_raw* out, float* fov);          /* Camera::to_raw */
+
 /* World::new (src/world.rs:34-40): 4 spheres, 3 materials drawn from a generator seeded with `seed`
  * (the reference uses the unseeded thread_rng, material.rs:22-37). */
 int rth_scene_default(uint64_t seed, rt_sphere* spheres4, rt_material* materials3);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "rt_sync": (C.c_int, [_VP]),
     "rt_read_rgba8": (C.c_int, [_VP, _VP, C.c_size_t]),
     "rt_read_accum_f32": (C.c_int, [_VP, _VP, C.c_size_t]),
+    "rt_write_image": (C.c_int, [_VP, _VP, C.c_size_t]),
     "rt_enable_rng_capture": (C.c_int, [_VP, C.c_int]),
     "rt_read_rng_state": (C.c_int, [_VP, _VP, C.c_size_t]),
     "rt_enable_counters": (C.c_int, [_VP, C.c_int]),

@@ -76,6 +76,11 @@ Mat4 Mat4::inverse() const {
   return inv;
 }
 
+Vec3 Mat4::transform_point3(Vec3 p) const {
+  return {((c[0] * p.x + c[4] * p.y) + c[8] * p.z) + c[12], ((c[1] * p.x + c[5] * p.y) + c[9] * p.z) + c[13],
+          ((c[2] * p.x + c[6] * p.y) + c[10] * p.z) + c[14]};
+}
+
 // ---------------------------------------------------------------------------------------------------
 uint64_t SeededRng::next_u64() {  // splitmix64
   uint64_t z = (s += 0x9e3779b97f4a7c15ull);
@@ -128,6 +133,44 @@ rt_camera_raw Camera::to_raw() const {
   r.frames_to_render = frames_to_render;
   r.current_frame = current_frame;
   return r;
+}
+
+void Camera::zoom(float val) {
+  const float pi = 3.14159265358979323846f;
+  const float old = std::log(std::tan(fov * pi / 2.0f));
+  const float nw = old + val / 5.0f;
+  fov = 2.0f * std::atan(std::exp(nw)) / pi;
+}
+
+void Camera::look_at_pixel_from_center(float off_x, float off_y) {
+  const Vec3 offset_3d{res_x / 2.0f + off_x, res_y / 2.0f + off_y, 0.0f};
+  const Mat4 pixel_to_world = calculate_world_to_pixel().inverse();
+  look_direction = normalize(pixel_to_world.transform_point3(offset_3d));
+}
+
+bool Camera::key_press(Key key) {
+  auto clampu = [](uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
+  auto move = [&](Vec3 dir) {
+    const Vec3 p = normalize(rotation_matrix().inverse().transform_point3(dir));
+    pos = {pos.x + p.x * speed, pos.y + p.y * speed, pos.z + p.z * speed};
+  };
+  switch (key) {
+    case Key::K: samples_per_pixel = clampu(samples_per_pixel * 2u, 1u, 256u); break;
+    case Key::J: samples_per_pixel = clampu(samples_per_pixel / 2u, 1u, 256u); break;
+    case Key::I: frames_to_render = clampu(frames_to_render * 2u, 1u, 256u); break;
+    case Key::U: frames_to_render = clampu(frames_to_render / 2u, 1u, 256u); break;
+    case Key::ArrowUp: zoom(-1.0f); break;
+    case Key::ArrowDown: zoom(1.0f); break;
+    case Key::Backspace: frames_to_render = 1; samples_per_pixel = 1; break;
+    case Key::W: move({0.f, 0.f, -1.f}); break;
+    case Key::S: move({0.f, 0.f, 1.f}); break;
+    case Key::D: move({1.f, 0.f, 0.f}); break;
+    case Key::A: move({-1.f, 0.f, 0.f}); break;
+    case Key::Space: move({0.f, 1.f, 0.f}); break;
+    case Key::ShiftLeft: move({0.f, -1.f, 0.f}); break;
+  }
+  reset_render();  // every handled key ends in scene_was_updated (camera.rs:172-174)
+  return true;
 }
 
 std::string Camera::to_string() const {
@@ -358,6 +401,40 @@ int rth_time_table(uint32_t start_bits, uint32_t n, uint32_t* out) {
     tm.add_delta(0.01f);
     out[i] = tm.bits();
   }
+  return RT_OK;
+}
+
+struct rth_camera {
+  rt::Camera cam;
+};
+
+rth_camera* rth_camera_create(uint32_t width, uint32_t height) { return (width && height) ? new rth_camera{rt::Camera(width, height)} : nullptr; }
+void rth_camera_destroy(rth_camera* c) { delete c; }
+int rth_camera_key(rth_camera* c, const char* key) {
+  if (!c || !key) { g_herr = "rth_camera_key: null argument"; return RT_ERR_INVALID; }
+  static const struct { const char* name; rt::Camera::Key k; } table[] = {
+      {"K", rt::Camera::Key::K}, {"J", rt::Camera::Key::J}, {"I", rt::Camera::Key::I}, {"U", rt::Camera::Key::U},
+      {"ArrowUp", rt::Camera::Key::ArrowUp}, {"ArrowDown", rt::Camera::Key::ArrowDown}, {"Backspace", rt::Camera::Key::Backspace},
+      {"W", rt::Camera::Key::W}, {"S", rt::Camera::Key::S}, {"D", rt::Camera::Key::D}, {"A", rt::Camera::Key::A},
+      {"Space", rt::Camera::Key::Space}, {"ShiftLeft", rt::Camera::Key::ShiftLeft}};
+  for (const auto& e : table)
+    if (std::strcmp(e.name, key) == 0) { c->cam.key_press(e.k); return RT_OK; }
+  g_herr = std::string("unknown key ") + key;
+  return RT_ERR_INVALID;
+}
+int rth_camera_zoom(rth_camera* c, float val) { if (!c) return RT_ERR_INVALID; c->cam.zoom(val); c->cam.reset_render(); return RT_OK; }
+int rth_camera_look_at_pixel(rth_camera* c, float off_x, float off_y) {
+  if (!c) return RT_ERR_INVALID;
+  c->cam.look_at_pixel_from_center(off_x, off_y);
+  c->cam.reset_render();
+  return RT_OK;
+}
+int rth_camera_increase_frame(rth_camera* c) { if (!c) return RT_ERR_INVALID; c->cam.increase_frame(); return RT_OK; }
+int rth_camera_render_finished(rth_camera* c) { return c && c->cam.render_finished() ? 1 : 0; }
+int rth_camera_get(rth_camera* c, rt_camera_raw* out, float* fov) {
+  if (!c || !out) { g_herr = "rth_camera_get: null argument"; return RT_ERR_INVALID; }
+  *out = c->cam.to_raw();
+  if (fov) *fov = c->cam.fov;
   return RT_OK;
 }
 

@@ -26,6 +26,7 @@ struct Mat4 {
   static Mat4 look_to_rh(Vec3 eye, Vec3 dir, Vec3 up);
   Mat4 operator*(const Mat4& rhs) const;
   Mat4 inverse() const;
+  Vec3 transform_point3(Vec3 p) const;  // (m * (p, 1)).xyz, no perspective divide (glam Mat4::transform_point3)
 };
 
 // ---- deterministic stand-in for rand::thread_rng (the reference's materials are unseeded and
@@ -59,6 +60,13 @@ class Camera {
   void reset_render() { current_frame = 0; }                  // camera.rs:274-277
   bool render_finished() const { return current_frame >= frames_to_render; }  // camera.rs:279-281
   std::string to_string() const;            // camera.rs:267-272
+  // headless forms of the interactive controls (no winit): each returns true when the scene changed,
+  // in which case the caller does what scene_was_updated does (reset_render + upload, camera.rs:283-288)
+  enum class Key { K, J, I, U, ArrowUp, ArrowDown, Backspace, W, S, D, A, Space, ShiftLeft };
+  bool key_press(Key key);                  // camera.rs:133-175 (one key, pressed and held)
+  void zoom(float val);                     // camera.rs:193-197
+  void look_at_pixel_from_center(float off_x, float off_y);  // camera.rs:200-206
+  float speed = 0.05f;
 
   Vec3 pos{0.f, 0.f, 0.f};
   float z_near = 1.0f, z_far = 100000.0f, fov = 0.25f;

@@ -378,6 +378,14 @@ int rt_read_accum_f32(rt_ctx* ctx, void* dst, size_t bytes) {
   return RT_OK;
 }
 
+int rt_write_image(rt_ctx* ctx, const void* src, size_t bytes) {
+  if (int rc = check(ctx)) return rc;
+  if (!src || bytes != ctx->accum_bytes) return fail(RT_ERR_INVALID, "rt_write_image: need exactly the image size of this context");
+  RT_HIP(hipMemcpyAsync(ctx->accum, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
 int rt_enable_rng_capture(rt_ctx* ctx, int enable) {
   if (int rc = check(ctx)) return rc;
   if (enable && !ctx->rng) {

@@ -15,6 +15,14 @@ _VP = C.c_void_p
 
 SIGNATURES = {
     "rth_camera_raw": (C.c_int, [C.c_uint32, C.c_uint32, _VP, _VP, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, _VP]),
+    "rth_camera_create": (_VP, [C.c_uint32, C.c_uint32]),
+    "rth_camera_destroy": (None, [_VP]),
+    "rth_camera_key": (C.c_int, [_VP, C.c_char_p]),
+    "rth_camera_zoom": (C.c_int, [_VP, C.c_float]),
+    "rth_camera_look_at_pixel": (C.c_int, [_VP, C.c_float, C.c_float]),
+    "rth_camera_increase_frame": (C.c_int, [_VP]),
+    "rth_camera_render_finished": (C.c_int, [_VP]),
+    "rth_camera_get": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
     "rth_scene_default": (C.c_int, [C.c_uint64, _VP, _VP]),
     "rth_scene_random_bunch": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, _VP, _VP]),
     "rth_time_table": (C.c_int, [C.c_uint32, C.c_uint32, _VP]),
@@ -91,6 +99,41 @@ def time_table(n, start_bits=0):
 def write_png(path, rgba8, present=False):
     a = np.ascontiguousarray(rgba8, np.uint8)
     _check(load().rth_write_png(os.fsencode(path), _p(a), a.shape[1], a.shape[0], int(present)))
+
+
+class Camera:
+    """Stateful headless Camera (reference camera.rs:23-288): keys, zoom, look-at-pixel, frame counter."""
+
+    def __init__(self, width, height):
+        self._lib = load()
+        self._h = _VP(self._lib.rth_camera_create(width, height))
+
+    def key(self, name):
+        _check(self._lib.rth_camera_key(self._h, name.encode()))
+
+    def zoom(self, val):
+        _check(self._lib.rth_camera_zoom(self._h, val))
+
+    def look_at_pixel(self, off_x, off_y):
+        _check(self._lib.rth_camera_look_at_pixel(self._h, off_x, off_y))
+
+    def increase_frame(self):
+        _check(self._lib.rth_camera_increase_frame(self._h))
+
+    def render_finished(self):
+        return bool(self._lib.rth_camera_render_finished(self._h))
+
+    def raw(self):
+        out = np.zeros(1, CAMERA_DTYPE)
+        fov = C.c_float()
+        _check(self._lib.rth_camera_get(self._h, _p(out), C.byref(fov)))
+        return out[0], fov.value
+
+    def __del__(self):
+        try:
+            self._lib.rth_camera_destroy(self._h)
+        except Exception:
+            pass
 
 
 class App:

@@ -110,6 +110,11 @@ class Raytracer:
         check(self._lib.rt_read_accum_f32(self._h, _ptr(out), out.nbytes))
         return out
 
+    def write_image(self, image):
+        """Upload a checkpointed image (uint8 HxWx4 for RGBA8 contexts, float32 HxWx4 for F32)."""
+        a = np.ascontiguousarray(image)
+        check(self._lib.rt_write_image(self._h, _ptr(a), a.nbytes))
+
     def enable_rng_capture(self, on=True):
         check(self._lib.rt_enable_rng_capture(self._h, int(on)))
 

@@ -273,3 +273,45 @@ def test_torch_owned_image_and_single_rank_rccl_reduce():
     assert np.array_equal(rt.read_accum_f32().view(np.uint32), ref.accum.view(np.uint32))
     rt.bind_accum(0, 0)  # back to the context's own image before the tensor dies
     rt.close()
+
+
+@pytest.mark.parametrize("flags", [0, O.ACCUM_F32], ids=["rgba8", "f32"])
+def test_checkpoint_resume_is_bit_identical(flags):
+    """Dump {image, current_frame, time bits} after 3 frames, resume in a fresh context for 3 more:
+    equals 6 frames straight (SURVEY.md §5 checkpoint/resume, §8f-4)."""
+    R = _rt()
+    W, H, spp, frames = 64, 48, 2, 6
+    spheres, mats = scenes.default_scene(1)
+    tb = O.time_bits_table(frames)
+    cam = scenes.camera_raw(W, H, spp=spp, frames=frames)
+    straight = _run_gpu(R, W, H, flags, spheres, mats, cam, frames, batched=True)
+    a = R.Raytracer(W, H, flags); a.set_scene(spheres, mats); a.set_camera(cam); a.render_frames(tb[:3])
+    ckpt = a.read_accum_f32() if flags & O.ACCUM_F32 else a.read_rgba8()
+    a.close()
+    b = R.Raytracer(W, H, flags); b.set_scene(spheres, mats); b.enable_rng_capture(True)
+    b.write_image(ckpt)
+    cam2 = np.array(cam, copy=True); cam2["current_frame"] = 3
+    b.set_camera(cam2); b.render_frames(tb[3:])
+    assert np.array_equal(b.read_rgba8(), straight.read_rgba8())
+    assert np.array_equal(b.read_rng_state(), straight.read_rng_state())
+    with pytest.raises(R.RtError):
+        b.write_image(ckpt[:10])
+    b.close(); straight.close()
+
+
+def test_degenerate_sizes_and_long_batches():
+    """Images smaller than one 16x16 workgroup render nothing under the reference's floor dispatch; a
+    batch longer than the initial frame-table capacity (256) grows it."""
+    R = _rt()
+    spheres, mats = scenes.default_scene(1)
+    rt = R.Raytracer(15, 40, 0); rt.set_scene(spheres, mats)
+    rt.set_camera(scenes.camera_raw(15, 40, spp=1, frames=2)); rt.set_time(0x3C23D70A); rt.compute()
+    assert not rt.read_rgba8().any()
+    rt.close()
+    W, H, frames = 32, 16, 300
+    cam = scenes.camera_raw(W, H, spp=1, frames=frames)
+    rt = _run_gpu(R, W, H, 0, spheres, mats, cam, frames, batched=True)
+    img = O.OracleImage(W, H, 0)
+    O.render(img, spheres, mats, cam, 0, frames)
+    assert np.array_equal(rt.read_rgba8(), img.rgba8) and np.array_equal(rt.read_rng_state(), img.rng)
+    rt.close()

@@ -98,3 +98,48 @@ def test_unorm8_load_formula_is_exact_for_all_256_values():
     src = open(os.path.join(os.path.dirname(__file__), "..", "raytracer_amd", "csrc", "rt_kernels.hip")).read()
     m = re.search(r"__builtin_fmaf\(f, (\S+)f, f \* (\S+)f\)", src)
     assert float.fromhex(m.group(1)) == float(c) and float.fromhex(m.group(2)) == float(c_lo)
+
+
+def test_camera_controls_match_the_reference_rules():
+    cam = host.Camera(640, 360)
+    raw, fov = cam.raw()
+    assert (int(raw["samples_per_pixel"]), int(raw["frames_to_render"]), fov) == (1, 8, 0.25)
+    for _ in range(10):
+        cam.key("K"); cam.key("I")  # x2, clamped to 256 (camera.rs:136,138)
+    raw, _ = cam.raw()
+    assert (int(raw["samples_per_pixel"]), int(raw["frames_to_render"])) == (256, 256)
+    cam.key("J"); cam.key("U")
+    raw, _ = cam.raw()
+    assert (int(raw["samples_per_pixel"]), int(raw["frames_to_render"])) == (128, 128)
+    cam.key("Backspace")
+    raw, _ = cam.raw()
+    assert (int(raw["samples_per_pixel"]), int(raw["frames_to_render"])) == (1, 1)
+    # frame counter: render_finished after frames_to_render increases; any control resets it (camera.rs:274-288)
+    assert not cam.render_finished()
+    cam.increase_frame()
+    assert cam.render_finished()
+    cam.key("W")
+    assert not cam.render_finished()
+    raw, _ = cam.raw()
+    assert np.allclose(raw["pos"], [0, 0, -0.05, -0.05], atol=1e-7)  # forward = -z, speed 0.05
+    cam.key("D"); cam.key("Space")
+    raw, _ = cam.raw()
+    assert np.allclose(raw["pos"][:3], [0.05, 0.05, -0.05], atol=1e-7)
+    # zoom: fov' = 2 atan(exp(ln tan(fov pi/2) + val/5)) / pi (camera.rs:193-197)
+    cam.zoom(1.0)
+    _, fov = cam.raw()
+    want = 2 * np.arctan(np.exp(np.log(np.tan(0.25 * np.pi / 2)) + 0.2)) / np.pi
+    assert abs(fov - want) < 1e-6
+    # looking at the centre pixel keeps the view direction; off-centre turns towards that pixel
+    c2 = host.Camera(640, 360)
+    before, _ = c2.raw()
+    c2.look_at_pixel(0.0, 0.0)
+    after, _ = c2.raw()
+    assert np.abs(before["pixel_to_world"] - after["pixel_to_world"]).max() < 1e-6
+    c2.look_at_pixel(100.0, 0.0)
+    turned, _ = c2.raw()
+    m = turned["pixel_to_world"].reshape(4, 4).T.astype(np.float64)
+    centre = (m @ np.array([320.0, 180.0, 0.0, 1.0]))[:3]
+    assert centre[0] > 0.05 and centre[2] < 0  # now looking to the right, still forward
+    ref = scenes.camera_raw(640, 360, look=centre / np.linalg.norm(centre))
+    assert np.abs(turned["pixel_to_world"] - ref["pixel_to_world"]).max() < 1e-5
