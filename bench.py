@@ -145,11 +145,21 @@ def cpu_baseline(cfg, flags, target_seconds):
         world = max(1, world // 8)
     rate = c["N"] / max(dt, 1e-6)
     want = int(max(1, min(4096, round(total / max(rate * target_seconds, 1.0)))))
+    frames = 1
     if want != world:
         world = want
         dt, c = run(world)
+    if world == 1 and dt < 0.6 * target_seconds:  # a whole frame is too short: time several
+        frames = int(min(8, max(2, round(target_seconds / dt))))
+        n = r = 0
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            _dt, cc = run(1)
+            n += cc["N"]; r += cc["R"]
+        dt = time.perf_counter() - t0
+        c = {"N": n, "R": r}
     return {"value": c["N"] / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"one frame, every {world}-th 8x8 tile of the {W}x{H} image at {spp} spp "
+            "sample": f"{frames} frame(s), every {world}-th 8x8 tile of the {W}x{H} image at {spp} spp "
                       f"({c['N']} samples, {c['R']} rays, {dt:.1f} s), oracle/rt_oracle.c with OpenMP",
             "rays_per_s": c["R"] / dt}
 
