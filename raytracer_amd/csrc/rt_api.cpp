@@ -43,6 +43,13 @@ struct rt_ctx {
   bool rng_capture = false;
   unsigned long long* counters = nullptr;
   uint32_t* queue = nullptr;  // tile queue head of the persistent kernel
+  // cost-ordered tile queue: per-tile cost of the last launch and the order derived from it
+  uint32_t* tile_cost = nullptr;
+  uint32_t* tile_order = nullptr;
+  uint32_t order_tiles = 0;   // my_tiles the buffers are sized for
+  uint32_t order_key = 0;     // rank/world the order was measured under
+  bool have_order = false;
+  int use_order = 1;          // env RT_TILE_ORDER=0 disables the feedback
   int compute_units = 0;
   int waves_per_cu = 0;       // launch width override (0 = default); env RT_WAVES_PER_CU
   int reject_tries = 0;       // rejection rounds override (0 = default); env RT_REJECT_TRIES
@@ -129,7 +136,8 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   if (my_tiles == 0) return RT_OK;
   // Rejection rounds per iteration: a lane that sits out pays one trace, so allow more rounds
   // the more a trace costs ("bounded rejection").
-  a.reject_tries = a.n_spheres <= 8u ? 2u : (a.n_spheres <= 64u ? 3u : 64u);
+  const bool strict_math = (ctx->flags & RT_MATH_FAST) == 0;
+  a.reject_tries = a.n_spheres <= 8u ? (strict_math ? 3u : 2u) : (a.n_spheres <= 64u ? 3u : 64u);
   if (ctx->reject_tries > 0) a.reject_tries = (uint32_t)ctx->reject_tries;
   // Persistent launch: enough single-wave workgroups to fill every SIMD, never more than tiles.
   const uint32_t wpc = ctx->waves_per_cu > 0 ? (uint32_t)ctx->waves_per_cu : 32u;
@@ -151,9 +159,34 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     RT_HIP(hipEventRecord(e0, ctx->stream));
   }
   const bool strict = (ctx->flags & RT_MATH_FAST) == 0;
+  // Cost-ordered queue (only worth it when there are more tiles than waves): hand tiles out dearest
+  // first, by the cost measured in the previous launch of the same partition.
+  const bool ordering = ctx->use_order && my_tiles > n_waves;
+  const uint32_t key = a.rank * 65536u + a.world;
+  if (ordering) {
+    if (ctx->order_tiles != my_tiles) {
+      RT_HIP(hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->tile_cost);
+      (void)hipFree(ctx->tile_order);
+      ctx->tile_cost = ctx->tile_order = nullptr;
+      RT_HIP(hipMalloc((void**)&ctx->tile_cost, my_tiles * sizeof(uint32_t)));
+      RT_HIP(hipMalloc((void**)&ctx->tile_order, my_tiles * sizeof(uint32_t)));
+      ctx->order_tiles = my_tiles;
+      ctx->have_order = false;
+    }
+    if (ctx->order_key != key) ctx->have_order = false;
+    ctx->order_key = key;
+    RT_HIP(hipMemsetAsync(ctx->tile_cost, 0, my_tiles * sizeof(uint32_t), ctx->stream));
+    a.tile_cost = ctx->tile_cost;
+    a.tile_order = ctx->have_order ? ctx->tile_order : nullptr;
+  }
   RT_HIP(hipMemsetAsync(ctx->queue, 0, sizeof(uint32_t), ctx->stream));
   RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, ctx->stream));
   if (ctx->timing) RT_HIP(hipEventRecord(e1, ctx->stream));
+  if (ordering) {
+    RT_HIP(rt_launch_tile_order(ctx->tile_cost, ctx->tile_order, my_tiles, ctx->stream));
+    ctx->have_order = true;
+  }
   return RT_OK;
 }
 
@@ -198,6 +231,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e1 = std::getenv("RT_WAVES_PER_CU")) c->waves_per_cu = std::atoi(e1);   // tuning knobs for experiments
   if (const char* e2 = std::getenv("RT_REJECT_TRIES")) c->reject_tries = std::atoi(e2);
   if (const char* e3 = std::getenv("RT_BATCH_LANES")) c->batch_lanes = std::atoi(e3);
+  if (const char* e4 = std::getenv("RT_TILE_ORDER")) c->use_order = std::atoi(e4);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
   if (e == hipSuccess) {
     c->stream = c->own_stream;
@@ -227,6 +261,8 @@ void rt_destroy(rt_ctx* c) {
   (void)hipFree(c->rng);
   (void)hipFree(c->counters);
   (void)hipFree(c->queue);
+  (void)hipFree(c->tile_cost);
+  (void)hipFree(c->tile_order);
   (void)hipFree(c->sph_test);
   (void)hipFree(c->sph_shade);
   (void)hipFree(c->sph_col);

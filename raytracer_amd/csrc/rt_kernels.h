@@ -35,8 +35,11 @@ struct rt_kargs {
   uint32_t* rng_out;             // optional
   unsigned long long* counters;  // 14 x u64, COUNT variants only
   uint32_t* queue;               // tile queue head, zeroed on the stream before every launch
+  const uint32_t* tile_order;    // optional: permutation of [0, my_tiles): queue position -> tile
+  uint32_t* tile_cost;           // optional: per-tile trace iterations of this launch (zeroed before it)
 };
 
 // n_waves persistent single-wave workgroups pull tiles from a.queue until a.my_tiles are handed out
 hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, hipStream_t stream);
+hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t n, hipStream_t stream);
 hipError_t rt_launch_quantize(const void* src_f32x4, void* dst_rgba8, size_t n_pixels, hipStream_t stream);

@@ -150,6 +150,9 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
   uint32_t state = ST_NEED_PIXEL;
   size_t pix = 0;            // pixel index v * width + u
   uint32_t seed_xy = 0;      // pixel part of the RNG seed
+  uint32_t my_tile = 0;      // index (in this rank's tile list) of the tile the pixel belongs to
+  uint32_t iters = 0;        // trace iterations spent on the current pixel (cost feedback for the tile order)
+  uint32_t q_tile = 0, q_tile_new = 0;  // wave-uniform: tile being handed out
   float pcx = 0, pcy = 0, pcz = 0, pdx = 0, pdy = 0, pdz = 0;  // pixel_center, pixel_delta
   float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;                // accumulation pixel
   uint32_t k = 0, rng = 0, sample = 0, depth = 0;
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
           reinterpret_cast<uint32_t*>(a.accum)[pix] = q8;
         }
         if (a.rng_out) a.rng_out[pix] = rng;
+        if (a.tile_cost) atomicAdd(&a.tile_cost[my_tile], iters);
         state = ST_NEED_PIXEL;
       } else {
         rng = seed_xy ^ a.frame_table[k].x;
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
       if (wants && my < avail) {  // a pixel of the tile already staged in LDS
         const uint32_t w = (q_cur + my) & 63u;
         rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
+        my_tile = q_tile;
         got = true;
       }
       if (n_need > avail) {
@@ -243,7 +248,10 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
           // ---- stage tile `base`: all 64 lanes compute the per-pixel constants of its 64 pixels at full
           // occupancy (pixel_to_world, get_pixel_delta wgsl:85-94; the pixel part of the RNG seed
           // wgsl:258-259) into LDS; lanes pick their record up when they are handed the pixel.
-          const uint32_t tile = base * a.world + a.rank;
+          // tiles are handed out in the order of the previous launch's measured cost, dearest first, so
+          // the launch ends on cheap pixels (results do not depend on the order)
+          q_tile_new = a.tile_order ? a.tile_order[base] : base;
+          const uint32_t tile = q_tile_new * a.world + a.rank;
           const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
           const uint32_t pu = tx * 8u + (lane & 7u), pv = ty * 8u + (lane >> 3);
           const float vx = (float)pu, vy = (float)(a.height - pv);
@@ -265,8 +273,10 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
           if (wants && !got) {
             const uint32_t w = my - avail;
             rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
+            my_tile = q_tile_new;
             got = true;
           }
+          q_tile = q_tile_new;
           q_cur = base * 64u + (n_need - avail);
           q_end = base * 64u + 64u;
         } else {
@@ -297,6 +307,7 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
           rng = rng_step(rng);  // initialize_rng's discarded rand() (wgsl:262)
           if (COUNT) c_rand++;
           sample = 0; sumx = sumy = sumz = 0.0f;
+          iters = 0;
           state = ST_NEW_RAY;
         }
       }
@@ -368,16 +379,18 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
     // ================= [C] trace + shade (lanes with a ray) =================
     if (COUNT && __ballot(state == ST_READY)) c_wt++;
     if (state == ST_READY) {
+      iters++;
       float closest = RT_RAY_TMAX;
       int hit = -1;
       const float a_fast = dot_fast(dx, dy, dz, dx, dy, dz);
-      float a_lit = a_fast, inv_a = 0.0f, a_margin = 0.0f;
+      float a_lit = a_fast, inv_a = 0.0f, a_margin = 0.0f, k_cc = 0.0f, k_rr = 0.0f;
       rn_divisor a_div = {1.0f, 1.0f, false};
       if (STRICT) {
         const float len = sqrt_rn(dot_strict(dx, dy, dz, dx, dy, dz));
         a_lit = len * len;  // length_squared (wgsl:306-309)
         a_div = make_divisor(a_lit);
         a_margin = a_fast * 0x1p-18f;
+        k_cc = a_margin - a_fast; k_rr = 2.0f * a_margin;
       } else {
         inv_a = __builtin_amdgcn_rcpf(a_fast);
       }
@@ -393,13 +406,16 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
           const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
           const float hb = dot_fast(ocx, ocy, ocz, dx, dy, dz);
           const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
-          float test = __builtin_fmaf(-a_fast, cc, hb * hb);
+          float test;
           if (STRICT) {
-            // |test - exact literal discriminant| < 24 * 2^-24 * a * (|oc|^2 + r^2) ("phase-1
-            // margin"); adding 2^-18 * a * (|oc|^2 + r^2) = a_margin * (cc + 2 r^2) makes a negative
-            // result a certain miss of the oracle's arithmetic too. A NaN produced here is the hardware
-            // default quiet NaN (sign 0), i.e. a candidate for the exact code.
-            test = __builtin_fmaf(a_margin, __builtin_fmaf(2.0f, s.w, cc), test);
+            // |fma(-a, cc, hb^2) - exact literal discriminant| < 24 * 2^-24 * a * (|oc|^2 + r^2) (DESIGN.md,
+            // "phase-1 margin"); adding m = 2^-18 * a * (|oc|^2 + r^2) = a_margin * (cc + 2 r^2) makes a
+            // negative result a certain miss of the oracle's arithmetic too. Folded into two FMAs:
+            // hb^2 - a cc + m = hb^2 + (2 a_margin) r^2 + (a_margin - a) cc. A NaN produced here is the
+            // hardware default quiet NaN (sign 0), i.e. a candidate for the exact code.
+            test = __builtin_fmaf(k_cc, cc, __builtin_fmaf(k_rr, s.w, hb * hb));
+          } else {
+            test = __builtin_fmaf(-a_fast, cc, hb * hb);
           }
           missbits = __builtin_amdgcn_alignbit(missbits, as_u32(test), 31);  // (missbits << 1) | sign(test)
         }
@@ -521,6 +537,37 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
   }
 }
 
+// Tile order for the next launch: counting sort of this launch's per-tile cost, dearest first.
+// One workgroup; order[] becomes a permutation of [0, n) whatever the costs are.
+__global__ __launch_bounds__(1024) void rt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n) {
+  __shared__ uint32_t s_max;
+  __shared__ uint32_t s_hist[256];
+  __shared__ uint32_t s_off[256];
+  const uint32_t t = threadIdx.x;
+  if (t == 0) s_max = 1u;
+  if (t < 256u) s_hist[t] = 0u;
+  __syncthreads();
+  uint32_t mx = 0;
+  for (uint32_t i = t; i < n; i += blockDim.x) mx = cost[i] > mx ? cost[i] : mx;
+  atomicMax(&s_max, mx);
+  __syncthreads();
+  const float scale = 255.0f / (float)s_max;
+  for (uint32_t i = t; i < n; i += blockDim.x) {
+    const uint32_t b = 255u - (uint32_t)((float)cost[i] * scale);  // bucket 0 = dearest
+    atomicAdd(&s_hist[b < 256u ? b : 0u], 1u);
+  }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t acc = 0;
+    for (int b = 0; b < 256; ++b) { s_off[b] = acc; acc += s_hist[b]; }
+  }
+  __syncthreads();
+  for (uint32_t i = t; i < n; i += blockDim.x) {
+    const uint32_t b = 255u - (uint32_t)((float)cost[i] * scale);
+    order[atomicAdd(&s_off[b < 256u ? b : 0u], 1u)] = i;
+  }
+}
+
 // RGBA8 view of a float4 accumulation image (rt_read_rgba8 on RT_ACCUM_F32 contexts)
 __global__ void rt_quantize_kernel(const f32x4* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -541,6 +588,12 @@ hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool stric
     if (count) hipLaunchKernelGGL((rt_path_kernel<false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rt_path_kernel<false, false>), grid, block, 0, stream, a);
   }
+  return hipGetLastError();
+}
+
+hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
   return hipGetLastError();
 }
 
