@@ -6,9 +6,12 @@
 
 A STEP is one compute pass (`rt_compute`, reference Raytracer::compute, src/raytracing.rs:178-200)
 over the whole image of the workload BASELINE.json's metric is quoted on: C3 = 3840x2160, 64 spp,
-glowing-checkers scene (random_bunch(20)). With N GPUs the image is split by interleaved 8x8 tiles
-(strong scaling: the 4K frame is fixed); the per-GPU images are combined by ONE RCCL sum-reduce at
-the end of the render, inside the timed region.
+glowing-checkers scene (random_bunch(20)). With N GPUs the progressive render is split by disjoint
+per-frame sample sets (BASELINE north_star's second partition): in step i rank r renders frame
+i*N + r of the whole 4K image into a float sum, so per-GPU work is fixed ("weak" scaling) and a step
+of the job is N frames; the per-GPU sums are combined by ONE RCCL sum-reduce at the end of the
+render, inside the timed region. `--split tiles` selects the image-tile partition instead (strong
+scaling on one frame; bit-identical to the 1-GPU image).
 
 Prints ONE JSON line (rank 0). `value` = covered pixels x spp x K / seconds, whole job, inputs
 resident in HBM, RT_MATH_STRICT (the mode that is bit-identical to the oracle). Extra objects:
@@ -46,7 +49,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--config", default="C3", help="C2 | C3 | C4 (C3 is the headline: 4K, 64 spp)")
     p.add_argument("--math", default="strict", choices=["strict", "fast"])
-    p.add_argument("--split", default="tiles", choices=["tiles", "frames"])
+    p.add_argument("--split", default="frames", choices=["tiles", "frames"],
+                   help="N > 1: frames = disjoint frame sets of the whole image per GPU (weak scaling, default); "
+                        "tiles = interleaved 8x8 tiles of one frame (strong scaling)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the fast_math side measurement")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
@@ -192,9 +197,9 @@ def main():
 
     cfg = configs.get(args.config)
     base_flags = cfg["flags"]
-    if args.split == "frames":
-        base_flags |= R.RT_ACCUM_F32 | R.RT_COMBINE_SUM
-    elif world > 1:
+    if args.split == "frames" and world > 1:
+        base_flags |= R.RT_ACCUM_F32 | R.RT_COMBINE_SUM  # per-GPU frame sums, one reduce, x 1/n afterwards
+    else:
         base_flags &= ~R.RT_COMBINE_SUM
 
     def run(math):
@@ -242,7 +247,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": m["seconds"] * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if args.split == "tiles" else "weak",
+            "scaling": "strong" if (args.split == "tiles" and world > 1) else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
