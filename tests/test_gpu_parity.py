@@ -315,3 +315,29 @@ def test_degenerate_sizes_and_long_batches():
     O.render(img, spheres, mats, cam, 0, frames)
     assert np.array_equal(rt.read_rgba8(), img.rgba8) and np.array_equal(rt.read_rng_state(), img.rng)
     rt.close()
+
+
+def test_cost_ordered_tile_queue_does_not_change_results(monkeypatch):
+    """With few persistent waves the queue hands tiles out in the previous launch's cost order; the
+    image and RNG states must not depend on it (launches 2.. run ordered)."""
+    R = _rt()
+    monkeypatch.setenv("RT_WAVES_PER_CU", "1")  # 256 waves for 1 800 tiles -> ordering is active
+    W, H, spp, frames = 480, 240, 2, 4
+    spheres, mats = scenes.default_scene(1)
+    cam = scenes.camera_raw(W, H, spp=spp, frames=frames)
+    img = O.OracleImage(W, H, 0)
+    ocam = np.array(cam, copy=True)
+    tb = O.time_bits_table(frames)
+
+    def check(f, rt):
+        O.compute(img, spheres, mats, ocam, int(tb[f]))
+        ocam["current_frame"] += 1
+        assert np.array_equal(rt.read_rng_state(), img.rng), f"frame {f}"
+        assert np.array_equal(rt.read_rgba8(), img.rgba8), f"frame {f}"
+
+    rt = _run_gpu(R, W, H, 0, spheres, mats, cam, frames, per_frame_check=check)
+    rt.close()
+    monkeypatch.setenv("RT_TILE_ORDER", "0")
+    rt2 = _run_gpu(R, W, H, 0, spheres, mats, cam, frames)
+    assert np.array_equal(rt2.read_rgba8(), img.rgba8)
+    rt2.close()
