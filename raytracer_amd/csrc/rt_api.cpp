@@ -49,13 +49,15 @@ struct rt_ctx {
   uint32_t order_tiles = 0;   // my_tiles the buffers are sized for
   uint32_t order_key = 0;     // rank/world the order was measured under
   bool have_order = false;
+  uint32_t order_age = 0;     // launches since the cost was last measured
   int use_order = 1;          // env RT_TILE_ORDER=0 disables the feedback
   int compute_units = 0;
   int waves_per_cu = 0;       // launch width override (0 = default); env RT_WAVES_PER_CU
   int reject_tries = 0;       // rejection rounds override (0 = default); env RT_REJECT_TRIES
   int batch_lanes = 0;        // parked-lane batch override (0 = default); env RT_BATCH_LANES
   bool counting = false;
-  rt_f32x4 *sph_test = nullptr, *sph_shade = nullptr, *sph_col = nullptr;
+  rt_f32x4 *sph_p1 = nullptr, *sph_test = nullptr, *sph_shade = nullptr, *sph_col = nullptr;
+  bool p1_tame = false;  // every sphere within the magnitude range of the phase-1 error bound
   uint32_t n_spheres = 0;
   bool have_scene = false, have_camera = false, have_time = false;
   rt_camera_raw camera{};
@@ -94,6 +96,8 @@ void covered(const rt_ctx* c, uint32_t* cov_w, uint32_t* cov_h) {
   }
 }
 
+constexpr uint32_t RT_ORDER_REFRESH = 32;  // launches between two measurements of the per-tile cost
+
 float frame_cw(uint32_t frame) {
   // combine_pixel_cache_color (wgsl:107-109): cw = f32(frame) / f32(frame + 1), one IEEE division
   const volatile float f = (float)frame, n = (float)(frame + 1u);
@@ -123,6 +127,8 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.batch_lanes = ctx->batch_lanes > 0 ? (uint32_t)ctx->batch_lanes : 1u;
   a.n_spheres = ctx->n_spheres;
   a.flags = ctx->flags;
+  a.p1_tame = ctx->p1_tame ? 1u : 0u;
+  a.sph_p1 = ctx->sph_p1;
   a.sph_test = ctx->sph_test;
   a.sph_shade = ctx->sph_shade;
   a.sph_col = ctx->sph_col;
@@ -160,8 +166,10 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   }
   const bool strict = (ctx->flags & RT_MATH_FAST) == 0;
   // Cost-ordered queue (only worth it when there are more tiles than waves): hand tiles out dearest
-  // first, by the cost measured in the previous launch of the same partition.
+  // first, by the cost measured in an earlier launch of the same partition, scene and camera. The
+  // measurement (one atomic per pixel) runs in the first launch and every RT_ORDER_REFRESH-th after.
   const bool ordering = ctx->use_order && my_tiles > n_waves;
+  bool measure = false;
   const uint32_t key = a.rank * 65536u + a.world;
   if (ordering) {
     if (ctx->order_tiles != my_tiles) {
@@ -176,16 +184,20 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     }
     if (ctx->order_key != key) ctx->have_order = false;
     ctx->order_key = key;
-    RT_HIP(hipMemsetAsync(ctx->tile_cost, 0, my_tiles * sizeof(uint32_t), ctx->stream));
-    a.tile_cost = ctx->tile_cost;
+    measure = !ctx->have_order || ++ctx->order_age >= RT_ORDER_REFRESH;
+    if (measure) {
+      RT_HIP(hipMemsetAsync(ctx->tile_cost, 0, my_tiles * sizeof(uint32_t), ctx->stream));
+      a.tile_cost = ctx->tile_cost;
+    }
     a.tile_order = ctx->have_order ? ctx->tile_order : nullptr;
   }
   RT_HIP(hipMemsetAsync(ctx->queue, 0, sizeof(uint32_t), ctx->stream));
   RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, ctx->stream));
   if (ctx->timing) RT_HIP(hipEventRecord(e1, ctx->stream));
-  if (ordering) {
+  if (measure) {
     RT_HIP(rt_launch_tile_order(ctx->tile_cost, ctx->tile_order, my_tiles, ctx->stream));
     ctx->have_order = true;
+    ctx->order_age = 0;
   }
   return RT_OK;
 }
@@ -263,6 +275,7 @@ void rt_destroy(rt_ctx* c) {
   (void)hipFree(c->queue);
   (void)hipFree(c->tile_cost);
   (void)hipFree(c->tile_order);
+  (void)hipFree(c->sph_p1);
   (void)hipFree(c->sph_test);
   (void)hipFree(c->sph_shade);
   (void)hipFree(c->sph_col);
@@ -278,7 +291,8 @@ int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, cons
   if (int rc = check(ctx)) return rc;
   if (!spheres || !materials || n_spheres == 0 || n_materials == 0) return fail(RT_ERR_INVALID, "empty scene");
   if (n_spheres > (1u << 24)) return fail(RT_ERR_INVALID, "too many spheres");
-  std::vector<rt_f32x4> test(n_spheres), shade(n_spheres), col(n_spheres);
+  std::vector<rt_f32x4> p1(n_spheres), test(n_spheres), shade(n_spheres), col(n_spheres);
+  bool tame = true;
   for (uint32_t i = 0; i < n_spheres; ++i) {
     const rt_sphere& s = spheres[i];
     if (s.material_index >= n_materials)
@@ -292,24 +306,35 @@ int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, cons
     int ex = 0;
     const bool pow2 = r > 0.0f && std::frexp((float)r, &ex) == 0.5f && ex > -100 && ex < 100;
     const float inv_r = pow2 ? 1.0f / r : -std::fabs(1.0f / r);
+    // phase-1 filter constant, from exact (double) |c|^2 and r^2, one rounding to f32:
+    // K' = (|c|^2 - r^2) - m (|c|^2 + r^2); the filter's error bound needs 2^-40 <= |c|^2 + r^2 <= 2^40
+    const double cc = (double)s.center[0] * s.center[0] + (double)s.center[1] * s.center[1] + (double)s.center[2] * s.center[2];
+    const double r2 = (double)s.radius * s.radius;
+    if (!(cc + r2 >= 0x1p-40 && cc + r2 <= 0x1p40)) tame = false;  // also catches NaN / inf
+    p1[i] = rt_f32x4{s.center[0], s.center[1], s.center[2], (float)((cc - r2) - (double)RT_P1_MARGIN * (cc + r2))};
     test[i] = rt_f32x4{s.center[0], s.center[1], s.center[2], rr};
     shade[i] = rt_f32x4{s.center[0], s.center[1], s.center[2], s.radius};
     col[i] = rt_f32x4{m.color[0], m.color[1], m.color[2], inv_r};
   }
   RT_HIP(hipStreamSynchronize(ctx->stream));  // no launch may still read the old arrays
+  (void)hipFree(ctx->sph_p1);
   (void)hipFree(ctx->sph_test);
   (void)hipFree(ctx->sph_shade);
   (void)hipFree(ctx->sph_col);
-  ctx->sph_test = ctx->sph_shade = ctx->sph_col = nullptr;
+  ctx->sph_p1 = ctx->sph_test = ctx->sph_shade = ctx->sph_col = nullptr;
   ctx->have_scene = false;
   const size_t bytes = (size_t)n_spheres * sizeof(rt_f32x4);
+  RT_HIP(hipMalloc((void**)&ctx->sph_p1, bytes));
   RT_HIP(hipMalloc((void**)&ctx->sph_test, bytes));
   RT_HIP(hipMalloc((void**)&ctx->sph_shade, bytes));
   RT_HIP(hipMalloc((void**)&ctx->sph_col, bytes));
+  RT_HIP(hipMemcpy(ctx->sph_p1, p1.data(), bytes, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(ctx->sph_test, test.data(), bytes, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(ctx->sph_shade, shade.data(), bytes, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(ctx->sph_col, col.data(), bytes, hipMemcpyHostToDevice));
   ctx->n_spheres = n_spheres;
+  ctx->p1_tame = tame;
+  ctx->have_order = false;  // per-tile cost belongs to the old scene
   ctx->have_scene = true;
   return RT_OK;
 }
@@ -319,6 +344,10 @@ int rt_set_camera(rt_ctx* ctx, const rt_camera_raw* camera) {
   if (!camera) return fail(RT_ERR_INVALID, "camera is null");
   if (camera->samples_per_pixel == 0)
     return fail(RT_ERR_INVALID, "samples_per_pixel must be >= 1 (the reference clamps it to [1,256], camera.rs:136-137)");
+  // a moved camera changes which tiles are dear: measure the per-tile cost again
+  if (!ctx->have_camera || std::memcmp(ctx->camera.pixel_to_world, camera->pixel_to_world, sizeof camera->pixel_to_world) != 0 ||
+      std::memcmp(ctx->camera.pos, camera->pos, sizeof camera->pos) != 0)
+    ctx->have_order = false;
   ctx->camera = *camera;
   ctx->have_camera = true;
   return RT_OK;

@@ -73,17 +73,29 @@ __device__ __forceinline__ float dot_fast(float ax, float ay, float az, float bx
   return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
 }
 
+// Rare-case handling in the helpers below is WAVE-UNIFORM: the common path is computed by every lane,
+// and the generic code sits behind `if (ballot(rare))`, one scalar branch. A per-lane `if` would cost
+// five to seven scalar instructions of exec-mask bookkeeping per call, and scalar instructions take
+// issue slots like vector ones (profiles/r1_valu_ubench.txt, "fma+salu").
+#ifndef RT_CULL_MAX
+#define RT_CULL_MAX 128u  // largest scene (spheres) for which the strict kernel culls spheres behind the ray in phase 1
+#endif
+#define RT_RARELY(cond) (__builtin_expect(__ballot(cond) != 0ull, 0))
+
 // Correctly rounded f32 square root (== the oracle's sqrtf). For x >= 2^-96 (and +inf / NaN) this is
 // the compiler's own expansion without its denormal pre-scaling and class fix-up: v_sqrt_f32 is
 // within 1 ulp, and the two FMA residuals pick the correctly rounded neighbour. Smaller x (0,
 // denormals, negatives) takes the generic path.
 __device__ __forceinline__ float sqrt_rn(float x) {
-  if (__builtin_expect(x < 0x1p-96f, 0)) return __builtin_sqrtf(x);
   const float s = __builtin_amdgcn_sqrtf(x);
   const float dn = as_f32(as_u32(s) - 1u), up = as_f32(as_u32(s) + 1u);
   const float rd = __builtin_fmaf(-dn, s, x), ru = __builtin_fmaf(-up, s, x);
   float r = rd <= 0.0f ? dn : s;
   r = ru > 0.0f ? up : r;
+  const bool rare = x < 0x1p-96f;
+  if (RT_RARELY(rare)) {
+    if (rare) r = __builtin_sqrtf(x);
+  }
   return r;
 }
 
@@ -100,13 +112,30 @@ __device__ __forceinline__ rn_divisor make_divisor(float y) {
   d.r = __builtin_fmaf(__builtin_fmaf(-y, r0, 1.0f), r0, r0);
   return d;
 }
-__device__ __forceinline__ float div_rn(float x, const rn_divisor& d) {
-  const float ax = __builtin_fabsf(x);
-  if (__builtin_expect(!(d.nice && ax >= 0x1p-60f && ax <= 0x1p60f), 0)) return x / d.y;
+__device__ __forceinline__ float div_core(float x, const rn_divisor& d) {
   float q = x * d.r;
   q = __builtin_fmaf(__builtin_fmaf(-d.y, q, x), d.r, q);
   q = __builtin_fmaf(__builtin_fmaf(-d.y, q, x), d.r, q);
   return q;
+}
+__device__ __forceinline__ float div_rn(float x, const rn_divisor& d) {
+  float q = div_core(x, d);
+  const float ax = __builtin_fabsf(x);
+  const bool rare = !(d.nice && ax >= 0x1p-60f && ax <= 0x1p60f);  // NaN operands are rare too
+  if (RT_RARELY(rare)) {
+    if (rare) q = x / d.y;
+  }
+  return q;
+}
+// x0 / y, x1 / y and x2 / y
+__device__ __forceinline__ void div3_rn(float x0, float x1, float x2, const rn_divisor& d, float& q0, float& q1, float& q2) {
+  q0 = div_core(x0, d); q1 = div_core(x1, d); q2 = div_core(x2, d);
+  const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(x0), __builtin_fabsf(x1)), __builtin_fabsf(x2));
+  const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)), __builtin_fabsf(x2));
+  const bool rare = !(d.nice && lo >= 0x1p-60f && hi <= 0x1p60f);
+  if (RT_RARELY(rare)) {
+    if (rare) { q0 = x0 / d.y; q1 = x1 / d.y; q2 = x2 / d.y; }
+  }
 }
 
 __device__ __forceinline__ uint32_t unorm8(float x) {  // rgba8unorm store: clamp (NaN -> 0), *255, RNE
@@ -121,16 +150,42 @@ __device__ __forceinline__ float unorm8_to_f32(uint32_t q) {
   return __builtin_fmaf(f, 0x1.010102p-8f, f * -0x1.fdfdfep-33f);
 }
 
+// Phase 1 of the hit loop for spheres base..base+cnt-1 (cnt <= 32): bit (cnt-1-j) of the result is 1 when
+// sphere base+j is a certain miss. Per sphere: 8 FMAs on scalar-loaded constants, [1 v_and_or], 1 v_alignbit.
+struct p1_ray { float dx, dy, dz, nod, na, nA, Px, Py, Pz; };
+template <bool CULL>
+__device__ __forceinline__ uint32_t phase1_missbits(const_f32x4_ptr sph_p1, uint32_t base, uint32_t cnt, const p1_ray& q) {
+  uint32_t missbits = 0xffffffffu;
+#pragma unroll 4
+  for (uint32_t j = 0; j < cnt; ++j) {
+    const f32x4 s = sph_p1[base + j];  // {cx, cy, cz, K'}: wave-uniform -> SGPRs
+    const float nhb = __builtin_fmaf(s.x, q.dx, __builtin_fmaf(s.y, q.dy, __builtin_fmaf(s.z, q.dz, q.nod)));  // -hb
+    float w = __builtin_fmaf(q.na, s.w, q.nA);
+    w = __builtin_fmaf(q.Px, s.x, w);
+    w = __builtin_fmaf(q.Py, s.y, w);
+    w = __builtin_fmaf(q.Pz, s.z, w);  // M - a (|o - c|^2 - r^2)
+    const float test = __builtin_fmaf(nhb, nhb, w);
+    // BEHIND CULL: w < 0 means the origin is outside the sphere by more than the margin; if then
+    // hb > 0 both roots are negative (the sphere lies behind the ray) and hit_sphere rejects them.
+    // Proof that the literal arithmetic agrees in DESIGN.md. One v_and_or: sign = (nhb & w) | test.
+    const uint32_t key = CULL ? ((as_u32(nhb) & as_u32(w)) | as_u32(test)) : as_u32(test);
+    missbits = __builtin_amdgcn_alignbit(missbits, key, 31);  // (missbits << 1) | sign
+  }
+  return missbits;
+}
+
 enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_READY = 2, ST_NEED_DIR = 3, ST_NEW_RAY = 4, ST_PATH_DONE = 5, ST_GOT_DIR = 6, ST_FRAME_END = 7 };
 
-template <bool STRICT, bool COUNT>
+// STRICT: arithmetic mode. COUNT: event counters for the roofline. CULL: phase 1 also drops spheres
+// behind the ray (strict, non-counting launches on small scenes; chosen by rt_launch_path_kernel).
+template <bool STRICT, bool COUNT, bool CULL>
 __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
   const uint32_t lane = threadIdx.x;
   const bool checker = (a.flags & RT_SHADE_CHECKER) != 0;
   const bool accum_f32 = (a.flags & RT_ACCUM_F32) != 0;
   const bool combine_sum = (a.flags & RT_COMBINE_SUM) != 0;
   const float* m = a.p2w;  // column-major
-  const const_f32x4_ptr sph_test = (const_f32x4_ptr)(uintptr_t)a.sph_test;
+  const const_f32x4_ptr sph_p1 = (const_f32x4_ptr)(uintptr_t)a.sph_p1;
   const uint32_t n_spheres = a.n_spheres;
   const float spp_f = (float)a.spp;
   __shared__ f32x4 tile_lds[128];  // per wave: 64 pixel records {pixel_center, v<<16|u} {pixel_delta, seed x^y}
@@ -368,7 +423,9 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
       // rec.normal + normalize(p) (wgsl:165,292-294), once per accepted lane after all rounds
       if (STRICT) {
         const rn_divisor len = make_divisor(sqrt_rn(gl2));
-        dx = dx + div_rn(gqx, len); dy = dy + div_rn(gqy, len); dz = dz + div_rn(gqz, len);
+        float ux, uy, uz;
+        div3_rn(gqx, gqy, gqz, len, ux, uy, uz);
+        dx = dx + ux; dy = dy + uy; dz = dz + uz;
       } else {
         const float il = __builtin_amdgcn_rsqf(gl2);
         dx = __builtin_fmaf(gqx, il, dx); dy = __builtin_fmaf(gqy, il, dy); dz = __builtin_fmaf(gqz, il, dz);
@@ -382,45 +439,40 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
       iters++;
       float closest = RT_RAY_TMAX;
       int hit = -1;
+      // ---- per-ray terms of the phase-1 filter ("phase-1 filter") ----
+      // exact discriminant D = hb^2 - a (|o - c|^2 - r^2), hb = o.d - c.d. With the margin
+      // M = m a (|o|^2 + |c|^2 + r^2), m = RT_P1_MARGIN:
+      //   D + M = (o.d - c.d)^2 + [(m - 1) a |o|^2] + (2 a o).c - a K',  K' = (|c|^2 - r^2) - m (|c|^2 + r^2)
+      // K' is a per-sphere constant (rt_set_scene), everything else per-ray: 8 FMAs per sphere. The
+      // computed value and the oracle's literal discriminant each stay within 54 resp. 47 units of
+      // 2^-24 a (|o|^2 + |c|^2 + r^2) of D while all magnitudes are `tame` (no overflow / underflow);
+      // m = 2^-16 = 256 such units, so a negative sign here is a certain miss of the literal code too.
+      // Rays or scenes outside the tame range skip the filter (every sphere is a candidate).
       const float a_fast = dot_fast(dx, dy, dz, dx, dy, dz);
-      float a_lit = a_fast, inv_a = 0.0f, a_margin = 0.0f, k_cc = 0.0f, k_rr = 0.0f;
+      const float oo = dot_fast(ox, oy, oz, ox, oy, oz);
+      const float nod = -dot_fast(ox, oy, oz, dx, dy, dz);
+      const bool tame = a.p1_tame != 0u && a_fast >= 0x1p-20f && a_fast <= 0x1p20f && oo <= 0x1p40f;
+      const float na = -a_fast;
+      const float nA = (a_fast * oo) * (RT_P1_MARGIN - 1.0f);
+      const float a2 = a_fast + a_fast;
+      const p1_ray p1q = {dx, dy, dz, nod, na, nA, a2 * ox, a2 * oy, a2 * oz};
+      float a_lit = a_fast, inv_a = 0.0f;
       rn_divisor a_div = {1.0f, 1.0f, false};
       if (STRICT) {
         const float len = sqrt_rn(dot_strict(dx, dy, dz, dx, dy, dz));
         a_lit = len * len;  // length_squared (wgsl:306-309)
         a_div = make_divisor(a_lit);
-        a_margin = a_fast * 0x1p-18f;
-        k_cc = a_margin - a_fast; k_rr = 2.0f * a_margin;
       } else {
         inv_a = __builtin_amdgcn_rcpf(a_fast);
       }
       if (COUNT) { c_R++; c_T += n_spheres; }
       for (uint32_t base = 0; base < n_spheres; base += 32u) {
         const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
-        // ---- phase 1: conservative discriminant sign of spheres base..base+cnt-1 -> bitmask ----
-        // bit (cnt-1-j) of `missbits` = sign of sphere (base+j)'s test value (1 = certain miss)
-        uint32_t missbits = 0xffffffffu;
-#pragma unroll 4
-        for (uint32_t j = 0; j < cnt; ++j) {
-          const f32x4 s = sph_test[base + j];  // {cx, cy, cz, r*r}: wave-uniform -> SGPRs
-          const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
-          const float hb = dot_fast(ocx, ocy, ocz, dx, dy, dz);
-          const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
-          float test;
-          if (STRICT) {
-            // |fma(-a, cc, hb^2) - exact literal discriminant| < 24 * 2^-24 * a * (|oc|^2 + r^2) (DESIGN.md,
-            // "phase-1 margin"); adding m = 2^-18 * a * (|oc|^2 + r^2) = a_margin * (cc + 2 r^2) makes a
-            // negative result a certain miss of the oracle's arithmetic too. Folded into two FMAs:
-            // hb^2 - a cc + m = hb^2 + (2 a_margin) r^2 + (a_margin - a) cc. A NaN produced here is the
-            // hardware default quiet NaN (sign 0), i.e. a candidate for the exact code.
-            test = __builtin_fmaf(k_cc, cc, __builtin_fmaf(k_rr, s.w, hb * hb));
-          } else {
-            test = __builtin_fmaf(-a_fast, cc, hb * hb);
-          }
-          missbits = __builtin_amdgcn_alignbit(missbits, as_u32(test), 31);  // (missbits << 1) | sign(test)
-        }
+        // ---- phase 1: sign of D + M for spheres base..base+cnt-1 -> bitmask ----
+        // bit (cnt-1-j) of `missbits` = sign of sphere (base+j)'s value (1 = certain miss)
+        const uint32_t missbits = phase1_missbits<CULL>(sph_p1, base, cnt, p1q);
         // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
-        uint32_t cand = ~missbits;
+        uint32_t cand = tame ? ~missbits : (cnt == 32u ? 0xffffffffu : (1u << cnt) - 1u);
         while (cand) {
           const uint32_t lz = (uint32_t)__builtin_clz(cand);
           cand &= ~(0x80000000u >> lz);
@@ -448,12 +500,14 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
             const float hb = dot_fast(ocx, ocy, ocz, dx, dy, dz);
             const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
             const float disc = __builtin_fmaf(-a_fast, cc, hb * hb);
-            if (COUNT) c_D++;
-            const float sq = __builtin_amdgcn_sqrtf(__builtin_fmaxf(disc, 0.0f));
-            const float r0 = (-hb - sq) * inv_a, r1 = (-hb + sq) * inv_a;
-            const bool ok0 = r0 > RT_RAY_TMIN && r0 < closest;
-            const float root = ok0 ? r0 : r1;
-            if (root > RT_RAY_TMIN && root < closest) { closest = root; hit = (int)i; }
+            if (!(disc < 0.0f)) {  // the filter's margin lets a few near misses through
+              if (COUNT) c_D++;
+              const float sq = __builtin_amdgcn_sqrtf(disc);
+              const float r0 = (-hb - sq) * inv_a, r1 = (-hb + sq) * inv_a;
+              const bool ok0 = r0 > RT_RAY_TMIN && r0 < closest;
+              const float root = ok0 ? r0 : r1;
+              if (root > RT_RAY_TMIN && root < closest) { closest = root; hit = (int)i; }
+            }
           }
         }
       }
@@ -486,7 +540,7 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
             nx = ex * sc.w; ny = ey * sc.w; nz = ez * sc.w;
           } else {
             const rn_divisor rd = make_divisor(sg.w);
-            nx = div_rn(ex, rd); ny = div_rn(ey, rd); nz = div_rn(ez, rd);
+            div3_rn(ex, ey, ez, rd, nx, ny, nz);
           }
         } else {
           px = __builtin_fmaf(closest, dx, ox); py = __builtin_fmaf(closest, dy, oy); pz = __builtin_fmaf(closest, dz, oz);
@@ -581,12 +635,16 @@ __global__ void rt_quantize_kernel(const f32x4* __restrict__ src, uint32_t* __re
 hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, hipStream_t stream) {
   if (n_waves == 0 || a.my_tiles == 0) return hipSuccess;
   const dim3 grid(n_waves), block(64);
+  // The behind cull saves exact tests (dear in strict mode, cheap in fast mode) for one more instruction
+  // per sphere test: used while the scene is small (measured: C3 20 spheres -3 %, C4 1024 spheres +2 %).
+  // Counting launches keep every candidate: the oracle's D counts their discriminants.
   if (strict) {
-    if (count) hipLaunchKernelGGL((rt_path_kernel<true, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((rt_path_kernel<true, false>), grid, block, 0, stream, a);
+    if (count) hipLaunchKernelGGL((rt_path_kernel<true, true, false>), grid, block, 0, stream, a);
+    else if (a.n_spheres <= RT_CULL_MAX) hipLaunchKernelGGL((rt_path_kernel<true, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((rt_path_kernel<true, false, false>), grid, block, 0, stream, a);
   } else {
-    if (count) hipLaunchKernelGGL((rt_path_kernel<false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((rt_path_kernel<false, false>), grid, block, 0, stream, a);
+    if (count) hipLaunchKernelGGL((rt_path_kernel<false, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((rt_path_kernel<false, false, false>), grid, block, 0, stream, a);
   }
   return hipGetLastError();
 }

@@ -22,11 +22,15 @@ def run(name, W, H, spp, scene, shade, math, reps=3, accum=R.RT_ACCUM_F32):
     c = rt.counters(); occ = rt.occupancy(); rt.enable_counters(False)
     fl = flops(c)
     rt.enable_timing(True)
-    for i in range(reps):
-        cam["current_frame"] = i + 1
-        rt.set_camera(cam); rt.set_time(int(tb[i + 1])); rt.compute()
-    ms, n = rt.timing()
-    ms /= n
+    best = 1e30
+    for batch in range(4):  # best of 4 batches: run-to-run noise is 1-2 %
+        rt.timing_reset()
+        for i in range(reps):
+            cam["current_frame"] = i + 1
+            rt.set_camera(cam); rt.set_time(int(tb[i + 1])); rt.compute()
+        ms, n = rt.timing()
+        best = min(best, ms / n)
+    ms = best
     samples = c["N"]
     print(f"{name:28s} {'fast' if math else 'strict':6s} {ms:9.3f} ms  {samples/ms/1e6:8.2f} Gsamples/s  {c['R']/ms/1e6:8.2f} Grays/s  "
           f"{fl/ms/1e9:7.2f} TFLOP/s ({fl/ms/1e9/157.3*100:5.1f}% of 157.3)  rays/sample {c['R']/samples:.2f} tests/ray {c['T']/c['R']:.0f} occ_trace {c['R']/max(occ['slots_trace'],1):.3f} occ_rej {c['J']/max(occ['slots_reject'],1):.3f} cand/ray {c['D']/c['R']:.2f}", flush=True)
