@@ -56,7 +56,8 @@ struct rt_ctx {
   int reject_tries = 0;       // rejection rounds override (0 = default); env RT_REJECT_TRIES
   int batch_lanes = 0;        // parked-lane batch override (0 = default); env RT_BATCH_LANES
   bool counting = false;
-  rt_f32x4 *sph_p1 = nullptr, *sph_test = nullptr, *sph_shade = nullptr, *sph_col = nullptr;
+  float* sph_p1 = nullptr;
+  rt_f32x4 *sph_test = nullptr, *sph_shade = nullptr, *sph_col = nullptr;
   bool p1_tame = false;  // every sphere within the magnitude range of the phase-1 error bound
   uint32_t n_spheres = 0;
   bool have_scene = false, have_camera = false, have_time = false;
@@ -291,7 +292,12 @@ int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, cons
   if (int rc = check(ctx)) return rc;
   if (!spheres || !materials || n_spheres == 0 || n_materials == 0) return fail(RT_ERR_INVALID, "empty scene");
   if (n_spheres > (1u << 24)) return fail(RT_ERR_INVALID, "too many spheres");
-  std::vector<rt_f32x4> p1(n_spheres), test(n_spheres), shade(n_spheres), col(n_spheres);
+  // phase-1 constants in sphere pairs {cx0,cx1, cy0,cy1, cz0,cz1, K'0,K'1}; the scene is padded to a multiple
+  // of four with spheres at the origin whose K' = 2^100 makes the filter value negative for every tame ray
+  const uint32_t n_pad = (n_spheres + 3u) & ~3u;
+  std::vector<float> p1((size_t)n_pad * 4u, 0.0f);
+  for (uint32_t i = n_spheres; i < n_pad; ++i) p1[(size_t)(i >> 1) * 8u + (i & 1u) + 6u] = 0x1p100f;
+  std::vector<rt_f32x4> test(n_spheres), shade(n_spheres), col(n_spheres);
   bool tame = true;
   for (uint32_t i = 0; i < n_spheres; ++i) {
     const rt_sphere& s = spheres[i];
@@ -311,7 +317,9 @@ int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, cons
     const double cc = (double)s.center[0] * s.center[0] + (double)s.center[1] * s.center[1] + (double)s.center[2] * s.center[2];
     const double r2 = (double)s.radius * s.radius;
     if (!(cc + r2 >= 0x1p-40 && cc + r2 <= 0x1p40)) tame = false;  // also catches NaN / inf
-    p1[i] = rt_f32x4{s.center[0], s.center[1], s.center[2], (float)((cc - r2) - (double)RT_P1_MARGIN * (cc + r2))};
+    float* pp = &p1[(size_t)(i >> 1) * 8u + (i & 1u)];
+    pp[0] = s.center[0]; pp[2] = s.center[1]; pp[4] = s.center[2];
+    pp[6] = (float)((cc - r2) - (double)RT_P1_MARGIN * (cc + r2));
     test[i] = rt_f32x4{s.center[0], s.center[1], s.center[2], rr};
     shade[i] = rt_f32x4{s.center[0], s.center[1], s.center[2], s.radius};
     col[i] = rt_f32x4{m.color[0], m.color[1], m.color[2], inv_r};
@@ -321,14 +329,15 @@ int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, cons
   (void)hipFree(ctx->sph_test);
   (void)hipFree(ctx->sph_shade);
   (void)hipFree(ctx->sph_col);
-  ctx->sph_p1 = ctx->sph_test = ctx->sph_shade = ctx->sph_col = nullptr;
+  ctx->sph_p1 = nullptr;
+  ctx->sph_test = ctx->sph_shade = ctx->sph_col = nullptr;
   ctx->have_scene = false;
   const size_t bytes = (size_t)n_spheres * sizeof(rt_f32x4);
-  RT_HIP(hipMalloc((void**)&ctx->sph_p1, bytes));
+  RT_HIP(hipMalloc((void**)&ctx->sph_p1, p1.size() * sizeof(float)));
   RT_HIP(hipMalloc((void**)&ctx->sph_test, bytes));
   RT_HIP(hipMalloc((void**)&ctx->sph_shade, bytes));
   RT_HIP(hipMalloc((void**)&ctx->sph_col, bytes));
-  RT_HIP(hipMemcpy(ctx->sph_p1, p1.data(), bytes, hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(ctx->sph_p1, p1.data(), p1.size() * sizeof(float), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(ctx->sph_test, test.data(), bytes, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(ctx->sph_shade, shade.data(), bytes, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(ctx->sph_col, col.data(), bytes, hipMemcpyHostToDevice));

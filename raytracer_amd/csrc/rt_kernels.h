@@ -11,8 +11,8 @@ typedef float rt_f32x4 __attribute__((ext_vector_type(4)));
 #define RT_P1_MARGIN 0x1p-16f
 
 // Kernel arguments (by value, lands in SGPRs). Scene arrays are the device-side re-layout built
-// by rt_set_scene: sph_p1[i] = {cx, cy, cz, (|c|^2 - r^2) - RT_P1_MARGIN * (|c|^2 + r^2)} (phase-1
-// filter, scalar loads), sph_test[i] = {cx, cy, cz, fl(r*r)} (exact test of the candidates),
+// by rt_set_scene: sph_p1[pair] = {cx0,cx1, cy0,cy1, cz0,cz1, K'0,K'1}, K' = (|c|^2 - r^2) - RT_P1_MARGIN *
+// (|c|^2 + r^2) (phase-1 filter, scalar loads, two spheres per packed instruction), sph_test[i] = {cx, cy, cz, fl(r*r)} (exact test of the candidates),
 // sph_shade[i] = {cx, cy, cz, r}, sph_col[i] = {material.color.rgb, +-fl(1/r)} (per-hit fetch).
 struct rt_kargs {
   float p2w[16];  // CameraRaw.pixel_to_world, column-major
@@ -33,7 +33,7 @@ struct rt_kargs {
   uint32_t n_spheres;
   uint32_t flags;
   uint32_t p1_tame;              // 1 when every sphere is inside the magnitude range the phase-1 error bound assumes
-  const rt_f32x4* sph_p1;
+  const float* sph_p1;           // n_spheres rounded up to a multiple of 4, x 4 floats
   const rt_f32x4* sph_test;
   const rt_f32x4* sph_shade;
   const rt_f32x4* sph_col;

@@ -150,29 +150,69 @@ __device__ __forceinline__ float unorm8_to_f32(uint32_t q) {
   return __builtin_fmaf(f, 0x1.010102p-8f, f * -0x1.fdfdfep-33f);
 }
 
-// Phase 1 of the hit loop for spheres base..base+cnt-1 (cnt <= 32): bit (cnt-1-j) of the result is 1 when
-// sphere base+j is a certain miss. Per sphere: 8 FMAs on scalar-loaded constants, [1 v_and_or], 1 v_alignbit.
-struct p1_ray { float dx, dy, dz, nod, na, nA, Px, Py, Pz; };
+// Phase 1 of the hit loop for spheres base..base+cnt-1 (base even, cnt <= 32), TWO SPHERES PER
+// INSTRUCTION: sph_p1 holds sphere pairs {cx0,cx1, cy0,cy1, cz0,cz1, K'0,K'1} (the scene is padded to a
+// multiple of four with spheres that always miss), loaded by scalar loads and used as the SGPR-pair source of
+// v_pk_fma_f32; the per-ray operands are broadcast out of VGPR pairs with op_sel. Per pair: 8 v_pk_fma
+// (measured 4.35 issue units against 2 x 3.25 for v_fma with an SGPR operand, profiles/r1_valu_ubench.txt),
+// [2 v_and_or], 2 v_alignbit. Bit (cnt_pad-1-j) of the result is 1 when sphere base+j is a certain miss,
+// cnt_pad = cnt rounded up to a multiple of four.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) f32x16* const_f32x16_ptr;
+struct p1_ray { f32x2 dx_dy, dz_nod, na_nA, Px_Py, Pz_0; };
+// d = s * broadcast(v.SEL1) + broadcast(c.SEL2) and d = s * broadcast(v.SEL) + d; s is an SGPR pair
+#define RT_PK_FMA_INIT(d, s, v, sel1, c, sel2) \
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0," #sel1 "," #sel2 "] op_sel_hi:[1," #sel1 "," #sel2 "]" : "=v"(d) : "s"(s), "v"(v), "v"(c))
+#define RT_PK_FMA_ACC(d, s, v, sel) \
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0," #sel ",0] op_sel_hi:[1," #sel ",1]" : "+v"(d) : "s"(s), "v"(v))
 template <bool CULL>
-__device__ __forceinline__ uint32_t phase1_missbits(const_f32x4_ptr sph_p1, uint32_t base, uint32_t cnt, const p1_ray& q) {
+__device__ __forceinline__ uint32_t phase1_pair(uint32_t missbits, f32x2 cx, f32x2 cy, f32x2 cz, f32x2 kk, const p1_ray& q) {
+  f32x2 nhb, w;
+  RT_PK_FMA_INIT(nhb, cz, q.dz_nod, 0, q.dz_nod, 1);  // -hb = c.d - o.d
+  RT_PK_FMA_ACC(nhb, cy, q.dx_dy, 1);
+  RT_PK_FMA_ACC(nhb, cx, q.dx_dy, 0);
+  RT_PK_FMA_INIT(w, kk, q.na_nA, 0, q.na_nA, 1);      // M - a (|o - c|^2 - r^2)
+  RT_PK_FMA_ACC(w, cx, q.Px_Py, 0);
+  RT_PK_FMA_ACC(w, cy, q.Px_Py, 1);
+  RT_PK_FMA_ACC(w, cz, q.Pz_0, 0);
+  const f32x2 test = __builtin_elementwise_fma(nhb, nhb, w);
+  // BEHIND CULL: w < 0 means the origin is outside the sphere by more than the margin; if then
+  // hb > 0 both roots are negative (the sphere lies behind the ray) and hit_sphere rejects them.
+  // Proof that the literal arithmetic agrees in DESIGN.md. One v_and_or: sign = (nhb & w) | test.
+  const uint32_t key0 = CULL ? ((as_u32(nhb.x) & as_u32(w.x)) | as_u32(test.x)) : as_u32(test.x);
+  const uint32_t key1 = CULL ? ((as_u32(nhb.y) & as_u32(w.y)) | as_u32(test.y)) : as_u32(test.y);
+  missbits = __builtin_amdgcn_alignbit(missbits, key0, 31);  // (missbits << 1) | sign
+  return __builtin_amdgcn_alignbit(missbits, key1, 31);
+}
+// spheres base..base+cnt_pad-1 (base, cnt_pad multiples of 4): one s_load_dwordx16 per four spheres
+template <bool CULL>
+__device__ __forceinline__ uint32_t phase1_missbits(const_f32x16_ptr sph_p1, uint32_t base, uint32_t cnt_pad, const p1_ray& q) {
   uint32_t missbits = 0xffffffffu;
-#pragma unroll 4
-  for (uint32_t j = 0; j < cnt; ++j) {
-    const f32x4 s = sph_p1[base + j];  // {cx, cy, cz, K'}: wave-uniform -> SGPRs
-    const float nhb = __builtin_fmaf(s.x, q.dx, __builtin_fmaf(s.y, q.dy, __builtin_fmaf(s.z, q.dz, q.nod)));  // -hb
-    float w = __builtin_fmaf(q.na, s.w, q.nA);
-    w = __builtin_fmaf(q.Px, s.x, w);
-    w = __builtin_fmaf(q.Py, s.y, w);
-    w = __builtin_fmaf(q.Pz, s.z, w);  // M - a (|o - c|^2 - r^2)
-    const float test = __builtin_fmaf(nhb, nhb, w);
-    // BEHIND CULL: w < 0 means the origin is outside the sphere by more than the margin; if then
-    // hb > 0 both roots are negative (the sphere lies behind the ray) and hit_sphere rejects them.
-    // Proof that the literal arithmetic agrees in DESIGN.md. One v_and_or: sign = (nhb & w) | test.
-    const uint32_t key = CULL ? ((as_u32(nhb) & as_u32(w)) | as_u32(test)) : as_u32(test);
-    missbits = __builtin_amdgcn_alignbit(missbits, key, 31);  // (missbits << 1) | sign
+  for (uint32_t j = 0; j < (cnt_pad >> 2); ++j) {
+    const f32x16 s = sph_p1[(base >> 2) + j];  // wave-uniform -> SGPRs
+    missbits = phase1_pair<CULL>(missbits, __builtin_shufflevector(s, s, 0, 1), __builtin_shufflevector(s, s, 2, 3),
+                                 __builtin_shufflevector(s, s, 4, 5), __builtin_shufflevector(s, s, 6, 7), q);
+    missbits = phase1_pair<CULL>(missbits, __builtin_shufflevector(s, s, 8, 9), __builtin_shufflevector(s, s, 10, 11),
+                                 __builtin_shufflevector(s, s, 12, 13), __builtin_shufflevector(s, s, 14, 15), q);
   }
   return missbits;
 }
+
+// Section timing for kernel studies (tools/section_profile.py): -DRT_PROFILE_SECTIONS=1 builds a library whose
+// path kernel adds the shader-clock cycles each wave spends in [G], the trace prelude, phase 1, phase 2
+// and shading into counters[0..4], its lifetime into [5], its loop iterations into [6] and its lifetime in
+// 100 MHz ticks into [7]. Not for production.
+#ifndef RT_PROFILE_SECTIONS
+#define RT_PROFILE_SECTIONS 0
+#endif
+#if RT_PROFILE_SECTIONS
+#define RT_PROF_BEGIN(i) const unsigned long long prof_b##i = __builtin_amdgcn_s_memtime()
+#define RT_PROF_END(i) prof_acc##i += __builtin_amdgcn_s_memtime() - prof_b##i
+#else
+#define RT_PROF_BEGIN(i)
+#define RT_PROF_END(i)
+#endif
 
 enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_READY = 2, ST_NEED_DIR = 3, ST_NEW_RAY = 4, ST_PATH_DONE = 5, ST_GOT_DIR = 6, ST_FRAME_END = 7 };
 
@@ -185,7 +225,7 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
   const bool accum_f32 = (a.flags & RT_ACCUM_F32) != 0;
   const bool combine_sum = (a.flags & RT_COMBINE_SUM) != 0;
   const float* m = a.p2w;  // column-major
-  const const_f32x4_ptr sph_p1 = (const_f32x4_ptr)(uintptr_t)a.sph_p1;
+  const const_f32x16_ptr sph_p1 = (const_f32x16_ptr)(uintptr_t)a.sph_p1;
   const uint32_t n_spheres = a.n_spheres;
   const float spp_f = (float)a.spp;
   __shared__ f32x4 tile_lds[128];  // per wave: 64 pixel records {pixel_center, v<<16|u} {pixel_delta, seed x^y}
@@ -216,7 +256,14 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
   float colx = 0, coly = 0, colz = 0, refl = 1.0f;             // ray_color's `color`, `reflectance`
   float gqx = 0, gqy = 0, gqz = 0, gl2 = 1.0f;                 // accepted point of random_in_unit_sphere, |q|^2
 
+#if RT_PROFILE_SECTIONS
+  unsigned long long prof_acc0 = 0, prof_acc1 = 0, prof_acc2 = 0, prof_acc3 = 0, prof_acc4 = 0, prof_iters = 0;
+  const unsigned long long prof_start = __builtin_amdgcn_s_memtime(), prof_rstart = __builtin_amdgcn_s_memrealtime();
+#endif
   for (;;) {
+#if RT_PROFILE_SECTIONS
+    prof_iters++;
+#endif
     // ================= [E] path end: next sample (cheap, every lane that finished a path) =================
     if (state == ST_PATH_DONE) {
       // send_rays: color += ray_color(ray) (wgsl:120)
@@ -373,6 +420,7 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
     // Round 0 is shared: lanes starting a sample draw the two jitter numbers of get_random_ray
     // (wgsl:174-180) with the same instructions that give lanes in random_in_unit_sphere
     // (wgsl:281-290) the first two of their three numbers. Further rounds serve NEED_DIR only.
+    RT_PROF_BEGIN(0);
     if (state == ST_NEW_RAY || state == ST_NEED_DIR) {
       float r0, r1;
       RT_RAND(r0); RT_RAND(r1);
@@ -433,9 +481,11 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
       state = depth > (uint32_t)RT_MAX_RAY_DEPTH ? ST_PATH_DONE : ST_READY;  // for (depth = 0; depth <= MAX_RAY_DEPTH; depth++) (wgsl:131)
     }
 
+    RT_PROF_END(0);
     // ================= [C] trace + shade (lanes with a ray) =================
     if (COUNT && __ballot(state == ST_READY)) c_wt++;
     if (state == ST_READY) {
+      RT_PROF_BEGIN(1);
       iters++;
       float closest = RT_RAY_TMAX;
       int hit = -1;
@@ -455,7 +505,7 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
       const float na = -a_fast;
       const float nA = (a_fast * oo) * (RT_P1_MARGIN - 1.0f);
       const float a2 = a_fast + a_fast;
-      const p1_ray p1q = {dx, dy, dz, nod, na, nA, a2 * ox, a2 * oy, a2 * oz};
+      const p1_ray p1q = {f32x2{dx, dy}, f32x2{dz, nod}, f32x2{na, nA}, f32x2{a2 * ox, a2 * oy}, f32x2{a2 * oz, 0.0f}};
       float a_lit = a_fast, inv_a = 0.0f;
       rn_divisor a_div = {1.0f, 1.0f, false};
       if (STRICT) {
@@ -466,17 +516,26 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
         inv_a = __builtin_amdgcn_rcpf(a_fast);
       }
       if (COUNT) { c_R++; c_T += n_spheres; }
+      RT_PROF_END(1);
       for (uint32_t base = 0; base < n_spheres; base += 32u) {
         const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
         // ---- phase 1: sign of D + M for spheres base..base+cnt-1 -> bitmask ----
-        // bit (cnt-1-j) of `missbits` = sign of sphere (base+j)'s value (1 = certain miss)
-        const uint32_t missbits = phase1_missbits<CULL>(sph_p1, base, cnt, p1q);
+        // bit (cnt_pad-1-j) of `missbits` = sign of sphere (base+j)'s value (1 = certain miss)
+        const uint32_t cnt_pad = (cnt + 3u) & ~3u;
+        RT_PROF_BEGIN(2);
+        const uint32_t missbits = phase1_missbits<CULL>(sph_p1, base, cnt_pad, p1q);
+#if RT_PROFILE_SECTIONS
+        asm volatile("" :: "v"(missbits));  // keep the loop inside the timed region
+#endif
+        RT_PROF_END(2);
+        RT_PROF_BEGIN(3);
         // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
-        uint32_t cand = tame ? ~missbits : (cnt == 32u ? 0xffffffffu : (1u << cnt) - 1u);
+        // (untamed rays take every sphere; the lowest cnt_pad - cnt bits are padding spheres)
+        uint32_t cand = tame ? ~missbits : ((cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u));
         while (cand) {
           const uint32_t lz = (uint32_t)__builtin_clz(cand);
           cand &= ~(0x80000000u >> lz);
-          const uint32_t i = base + cnt - 32u + lz;
+          const uint32_t i = base + cnt_pad - 32u + lz;
           const f32x4 s = a.sph_test[i];
           const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
           if (STRICT) {
@@ -510,8 +569,10 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
             }
           }
         }
+        RT_PROF_END(3);
       }
 
+      RT_PROF_BEGIN(4);
       if (hit < 0) {
         // miss (wgsl:144-148); ray_color: color += miss * reflectance; break
         if (COUNT) c_M++;
@@ -577,9 +638,25 @@ __global__ __launch_bounds__(64) void rt_path_kernel(const rt_kargs a) {
           state = ST_NEED_DIR;
         }
       }
+      RT_PROF_END(4);
     }
   }
 
+#if RT_PROFILE_SECTIONS
+  if (lane == 0) {
+    const unsigned long long life = __builtin_amdgcn_s_memtime() - prof_start;
+    const unsigned long long rlife = __builtin_amdgcn_s_memrealtime() - prof_rstart;  // 100 MHz
+    const unsigned long long pv[8] = {prof_acc0, prof_acc1, prof_acc2, prof_acc3, prof_acc4, life, prof_iters, rlife};
+    for (int i = 0; i < 8; ++i) atomicAdd(&a.counters[i], pv[i]);
+    // launch shape: [8] = ~min start, [9] = max end, [10] = sum of starts, [11] = sum of ends (100 MHz ticks),
+    // [12] = waves that found the queue empty on arrival
+    atomicMax(&a.counters[8], ~prof_rstart);
+    atomicMax(&a.counters[9], prof_rstart + rlife);
+    atomicAdd(&a.counters[10], prof_rstart & 0xffffffffull);
+    atomicAdd(&a.counters[11], (prof_rstart + rlife) & 0xffffffffull);
+    if (prof_iters <= 2) atomicAdd(&a.counters[12], 1ull);
+  }
+#endif
   if (COUNT) {
     const uint32_t vals[12] = {c_T, c_D, c_H, c_R, c_M, c_S, c_Sm, c_J, c_Sd, c_N, c_P, c_rand};
 #pragma unroll

@@ -341,3 +341,63 @@ def test_cost_ordered_tile_queue_does_not_change_results(monkeypatch):
     rt2 = _run_gpu(R, W, H, 0, spheres, mats, cam, frames)
     assert np.array_equal(rt2.read_rgba8(), img.rgba8)
     rt2.close()
+
+
+def _strict_equals_oracle(R, W, H, spp, frames, flags, spheres, mats, cam, counters):
+    """Strict launch(es) against the oracle: image, RNG states (and counters when counting, which also
+    selects the kernel variant without the behind-the-ray cull)."""
+    img = O.OracleImage(W, H, flags)
+    O.render(img, spheres, mats, cam, 0, frames)
+    rt = _run_gpu(R, W, H, flags | R.RT_MATH_STRICT, spheres, mats, cam, frames, counters=counters)
+    assert np.array_equal(rt.read_rng_state(), img.rng)
+    if flags & O.ACCUM_F32:
+        assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
+    assert np.array_equal(rt.read_rgba8(), img.view_rgba8())
+    if counters:
+        assert rt.counters() == img.counters_dict()
+    rt.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 31, 32, 33, 35, 64, 65, 127, 128, 129, 130])
+def test_sphere_counts_around_the_pair_and_group_sizes(n):
+    """Phase 1 handles spheres four at a time (padding spheres that never hit) in groups of 32, and
+    switches the behind cull off above 128 spheres: every remainder must give the oracle's image."""
+    R = _rt()
+    spheres, mats = scenes.random_bunch(n, 3, 100 + n)
+    cam = scenes.camera_raw(64, 48, spp=2, frames=2)
+    for counters in (False, True):
+        _strict_equals_oracle(R, 64, 48, 2, 2, O.ACCUM_F32, spheres, mats, cam, counters)
+
+
+def _edge_scene(name):
+    mats = scenes.make_materials(np.random.RandomState(5).random_sample((3, 4)).astype(np.float32))
+    if name == "camera_inside_a_sphere":      # origin inside: no cull, hits from the inside, second roots
+        return scenes.make_spheres([(0, 0, 0), (0.5, 0, -2), (-0.7, 0.2, -2.5)], [6.0, 0.5, 0.75], [0, 1, 2]), mats, {}
+    if name == "coincident_and_touching":     # equal roots, tangent spheres, one sphere inside another
+        return scenes.make_spheres([(0, 0, -3), (0, 0, -3), (1.0, 0, -3), (0, 0, -3), (0, -1.5, -3)],
+                                   [0.5, 0.5, 0.5, 0.25, 1.0], [0, 1, 2, 0, 1]), mats, {}
+    if name == "tiny_and_huge_radii":
+        return scenes.make_spheres([(0, 0, -2), (0.3, 0.1, -1.5), (0, -1000.5, -2), (0, 0, -50)],
+                                   [1e-3, 0.125, 1000.0, 30.0], [0, 1, 2, 0]), mats, {}
+    if name == "far_from_the_origin":         # |c|^2 ~ 3e6: the margin is relative to |o|^2 + |c|^2 + r^2
+        c0 = np.array([1000.0, 1000.0, -1000.0])
+        s, _ = scenes.random_bunch(9, 3, 7)
+        s["center"] += c0.astype(np.float32)
+        s["padding"] = s["center"][:, 2].copy().view(np.uint32)
+        return s, mats, {"pos": tuple(c0)}
+    if name == "outside_the_tame_range":      # |c|^2 > 2^40: the filter is skipped, every sphere is tested exactly
+        return scenes.make_spheres([(0, 0, -3), (2.0e6, 0, -3), (0.6, 0.1, -2)], [1.0, 1.0e6, 0.25], [0, 1, 2]), mats, {}
+    if name == "degenerate_radius_zero":
+        return scenes.make_spheres([(0, 0, -3), (0.2, 0.2, -2)], [0.0, 0.5], [0, 1]), mats, {}
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["camera_inside_a_sphere", "coincident_and_touching", "tiny_and_huge_radii",
+                                  "far_from_the_origin", "outside_the_tame_range", "degenerate_radius_zero"])
+def test_phase1_filter_edge_scenes(name):
+    """Scenes that stress the phase-1 filter (margin, behind cull, tame range): results stay the oracle's."""
+    R = _rt()
+    spheres, mats, camkw = _edge_scene(name)
+    cam = scenes.camera_raw(64, 48, spp=3, frames=2, **camkw)
+    for counters in (False, True):
+        _strict_equals_oracle(R, 64, 48, 3, 2, O.ACCUM_F32, spheres, mats, cam, counters)

@@ -93,6 +93,11 @@ __global__ __launch_bounds__(64) void k(float* out, float s0, int n, unsigned lo
       BODY8(OP)
 #undef OP
       u[0] += sa + sb;
+    } else if (KIND == 17) {  // v_pk_fma_f32 with an SGPR-pair source and broadcast (op_sel) VGPR sources, as a packed hit loop would use
+      f2 sc = f2{c0, c1};
+#define OP(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(p[i]) : "s"(sc), "v"(p[(i + 1) & 7])); asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(p[i]) : "s"(sc), "v"(p[(i + 2) & 7]));
+      BODY8(OP)
+#undef OP
     } else if (KIND == 16) {  // v_fma + exec-mask juggling as a divergent `if` compiles to (v_cmp, s_and_saveexec, s_or)
 #define OP(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(q[i]), "v"(c1)); asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\ts_and_saveexec_b64 s[20:21], vcc\n\tv_fma_f32 %0, %0, %2, %1\n\ts_or_b64 exec, exec, s[20:21]" : "+v"(q[i]) : "v"(c1), "v"(c0) : "vcc", "s20", "s21");
       BODY8(OP)
@@ -133,9 +138,9 @@ int main() {
   float* d; CHECK(hipMalloc(&d, 4));
   unsigned long long* st; CHECK(hipMalloc(&st, 16));
   const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_subrev_f32(sgpr)", "v_alignbit_b32", "v_mul_lo_u32", "v_sqrt_f32", "v_rcp_f32",
-                         "v_lshlrev+v_xor", "v_cmp+v_cndmask", "v_mad_u32_u24", "v_mul_f32", "v_fma_f32(sgpr)", "v_pk_mul/add_f32", "v_fma_f32 dep-chain", "fma+salu 1:1 (per fma)", "fma+salu 2:1 (per fma)", "fma,[cmp,saveexec,fma,or]"};
+                         "v_lshlrev+v_xor", "v_cmp+v_cndmask", "v_mad_u32_u24", "v_mul_f32", "v_fma_f32(sgpr)", "v_pk_mul/add_f32", "v_fma_f32 dep-chain", "fma+salu 1:1 (per fma)", "fma+salu 2:1 (per fma)", "fma,[cmp,saveexec,fma,or]", "v_pk_fma_f32(sgpr pair,bcast)"};
   printf("%-22s %8s %8s %8s %8s   (cycles @2.4GHz per wave64 instruction per SIMD)\n", "instruction", "1w/SIMD", "2w", "4w", "8w");
 #define ROW(K) { printf("%-22s", names[K]); for (int w : {1, 2, 4, 8}) { double g, c; double x = run<K>(w, d, cus, st, &g, &c); printf(" %6.2f (%4.2f real @%4.2fGHz)", x, c, g); } printf("\n"); }
-  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12) ROW(13) ROW(14) ROW(15) ROW(16)
+  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12) ROW(13) ROW(14) ROW(15) ROW(17)
   return 0;
 }
