@@ -147,7 +147,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.reject_tries = a.n_spheres <= 8u ? (strict_math ? 3u : 2u) : (a.n_spheres <= 64u ? 3u : 64u);
   if (ctx->reject_tries > 0) a.reject_tries = (uint32_t)ctx->reject_tries;
   // Persistent launch: enough single-wave workgroups to fill every SIMD, never more than tiles.
-  const uint32_t wpc = ctx->waves_per_cu > 0 ? (uint32_t)ctx->waves_per_cu : 32u;
+  const uint32_t wpc = ctx->waves_per_cu > 0 ? (uint32_t)ctx->waves_per_cu : 24u;  // 6 waves per SIMD are resident (<= 80 VGPRs)
   const uint64_t resident = (uint64_t)ctx->compute_units * wpc;
   const uint32_t n_waves = (uint32_t)(resident < my_tiles ? resident : my_tiles);
   // host-side shape check before the launch: every tile index a block can form is < n_tiles or

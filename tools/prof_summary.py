@@ -13,10 +13,12 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recurs
         print("dispatch:", {k: r[k] for k in r if k in ("Kernel_Name", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size", "Start_Timestamp", "End_Timestamp")})
 sums = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(lambda: collections.defaultdict(int))
+each = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"][:60]
+        k = row["Kernel_Name"][:80]
         sums[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        each[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         calls[k][row["Counter_Name"]] += 1
 for k in sums:
     print("== PMC per dispatch (mean):", k)
@@ -27,12 +29,16 @@ for k in sums:
 # Calibration (MI355X_MICROARCH.md, HBM): a read request is a 128-B line tallied at 64 B, i.e. bytes read
 # = RDREQ x 128 (here: 8 float4 pixels per line -> W*H/8 requests, which matches the count exactly);
 # a write request is 64 B.
-import json
+# The MEDIAN launch is reported: one launch in 32 also measures the per-tile cost (one atomic per pixel,
+# +64 B of write traffic each); its figure is listed as "cost_measuring_launch".
+import json, re, statistics
 for k in sums:
-    if "rt_path_kernel" in k and ", false>" in k and "TCC_EA0_RDREQ_sum" in sums[k]:
-        rd = sums[k]["TCC_EA0_RDREQ_sum"] / calls[k]["TCC_EA0_RDREQ_sum"]
-        wr = sums[k]["TCC_EA0_WRREQ_sum"] / calls[k]["TCC_EA0_WRREQ_sum"]
+    if re.search(r"rt_path_kernel<(true|false), false", k) and "TCC_EA0_RDREQ_sum" in sums[k]:
+        rd = statistics.median(each[k]["TCC_EA0_RDREQ_sum"])
+        wr = statistics.median(each[k]["TCC_EA0_WRREQ_sum"])
         t = {"kernel": k, "rdreq_per_launch": rd, "wrreq_per_launch": wr, "bytes_per_launch": rd * 128 + wr * 64,
-             "rule": "RDREQ x 128 B + WRREQ x 64 B (separate --pmc pass, TCC_EA0_RDREQ_sum / TCC_EA0_WRREQ_sum)"}
+             "cost_measuring_launch_bytes": max(each[k]["TCC_EA0_RDREQ_sum"]) * 128 + max(each[k]["TCC_EA0_WRREQ_sum"]) * 64,
+             "launches": len(each[k]["TCC_EA0_RDREQ_sum"]),
+             "rule": "RDREQ x 128 B + WRREQ x 64 B (separate --pmc pass, TCC_EA0_RDREQ_sum / TCC_EA0_WRREQ_sum), median launch"}
         json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
         print("traffic:", t)
