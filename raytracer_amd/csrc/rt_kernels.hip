@@ -12,10 +12,10 @@
 //  * ONE FLAT LOOP PER LANE. Frame loop, sample loop and bounce loop of a pixel are flattened into
 //    a loop of trace() iterations with path regeneration. Every lane still consumes its own RNG
 //    stream in the reference's order, so results do not depend on which lane renders a pixel.
-//  * TWO-PHASE HIT LOOP. Phase 1 walks the spheres with a wave-uniform index: test data
-//    {cx,cy,cz,r*r} arrives by scalar loads and is used straight from SGPRs, 12 VALU ops per
-//    sphere, no branch; the sign bit of a conservative discriminant is shifted into a per-lane
-//    32-sphere bitmask (v_alignbit). Phase 2 lets every lane walk ITS OWN candidate bits (gathered
+//  * TWO-PHASE HIT LOOP. Phase 1 walks the spheres with a wave-uniform index: per-sphere constants
+//    arrive by scalar loads and are used straight from SGPR pairs, two spheres per v_pk_fma_f32,
+//    5-6 VALU instructions per sphere, no branch; the sign bit of a conservative discriminant is
+//    shifted into a per-lane 32-sphere bitmask (v_alignbit). Phase 2 lets every lane walk ITS OWN candidate bits (gathered
 //    loads), so the expensive root code (sqrt, divisions) runs at full lane occupancy instead of
 //    once per sphere that any lane of the wave might hit.
 //  * BOUNDED REJECTION SAMPLING. random_in_unit_sphere (p = pi/6) runs at most `reject_tries`
@@ -25,7 +25,7 @@
 //
 // Two arithmetic modes (rt_types.h). RT_MATH_STRICT: phase 2, shading and accumulation restate
 // the oracle's IEEE contract operation by operation (bit-identical images and RNG states); phase 1
-// only has to be a superset filter, so it shares the fast FMA form plus a proven error margin.
+// only has to be a superset filter, so both modes share one FMA form with a proven error margin.
 // RT_MATH_FAST: FMA, v_rcp/v_rsq/v_sqrt, dot() for length_squared.
 // This file must be compiled with -ffp-contract=off: every fused operation is written explicitly.
 #include <hip/hip_runtime.h>
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
       // M = m a (|o|^2 + |c|^2 + r^2), m = RT_P1_MARGIN:
       //   D + M = (o.d - c.d)^2 + [(m - 1) a |o|^2] + (2 a o).c - a K',  K' = (|c|^2 - r^2) - m (|c|^2 + r^2)
       // K' is a per-sphere constant (rt_set_scene), everything else per-ray: 8 FMAs per sphere. The
-      // computed value and the oracle's literal discriminant each stay within 54 resp. 47 units of
+      // computed value and the oracle's literal discriminant each stay within 51 resp. 54 units of
       // 2^-24 a (|o|^2 + |c|^2 + r^2) of D while all magnitudes are `tame` (no overflow / underflow);
       // m = 2^-16 = 256 such units, so a negative sign here is a certain miss of the literal code too.
       // Rays or scenes outside the tame range skip the filter (every sphere is a candidate).
