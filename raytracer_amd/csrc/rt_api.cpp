@@ -125,7 +125,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.cw0 = frame_cw(first_frame);
   a.frame_table = time_table_dev;
   a.inv_spp = (a.spp & (a.spp - 1u)) == 0u ? 1.0f / (float)a.spp : 0.0f;
-  a.batch_lanes = ctx->batch_lanes > 0 ? (uint32_t)ctx->batch_lanes : 1u;
+  a.batch_lanes = ctx->batch_lanes > 0 ? (uint32_t)ctx->batch_lanes : 3u;  // profiles/r1b_sweep_batch_lanes.log
   a.n_spheres = ctx->n_spheres;
   a.flags = ctx->flags;
   a.p1_tame = ctx->p1_tame ? 1u : 0u;

@@ -49,11 +49,16 @@ __device__ __forceinline__ uint32_t rng_step(uint32_t rng) {
   rng ^= (rng << 4);
   return rng;
 }
-__device__ __forceinline__ float rng_unit(uint32_t rng) { return as_f32((rng & 0x007fffffu) | 0x3f800000u) - 1.0f; }
-#define RT_RAND(dst)        \
+// The two uses of rand() (wgsl:174-180, 281-290) as ONE exact subtraction each. With m = k 2^-23 the
+// 23 mantissa bits k of the state, rand() = m exactly, and both -0.5 + m = (k - 2^22) 2^-23 and
+// 2 m - 1 = (2k - 2^23) 2^-23 are representable, so every correctly rounded way of computing them gives
+// the same bits: (1 + m) - 1.5 and (2 + 2m) - 3, the left operands being bit patterns.
+__device__ __forceinline__ float rng_jitter(uint32_t rng) { return as_f32((rng & 0x007fffffu) | 0x3f800000u) - 1.5f; }
+__device__ __forceinline__ float rng_signed(uint32_t rng) { return as_f32((rng & 0x007fffffu) | 0x40000000u) - 3.0f; }
+#define RT_STEP(dst)        \
   do {                      \
     rng = rng_step(rng);    \
-    (dst) = rng_unit(rng);  \
+    (dst) = rng;            \
     if (COUNT) c_rand++;    \
   } while (0)
 
@@ -425,27 +430,21 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
     // (wgsl:281-290) the first two of their three numbers. Further rounds serve NEED_DIR only.
     RT_PROF_BEGIN(0);
     if (state == ST_NEW_RAY || state == ST_NEED_DIR) {
-      float r0, r1;
-      RT_RAND(r0); RT_RAND(r1);
+      uint32_t s0, s1;
+      RT_STEP(s0); RT_STEP(s1);
       if (state == ST_NEW_RAY) {
-        const float px = -0.5f + r0, py = -0.5f + r1;
+        const float px = rng_jitter(s0), py = rng_jitter(s1);
         dx = pcx + px * pdx; dy = pcy + py * pdy; dz = pcz + 1.0f * pdz;
         ox = a.pos[0]; oy = a.pos[1]; oz = a.pos[2];
         colx = coly = colz = 0.0f; refl = 1.0f; depth = 0;
         if (COUNT) c_N++;
         state = ST_READY;
       } else {
-        float r2;
-        RT_RAND(r2);
+        uint32_t s2;
+        RT_STEP(s2);
         if (COUNT) c_J++;
-        float qx, qy, qz, l2;
-        if (STRICT) {
-          qx = r0 * 2.0f - 1.0f; qy = r1 * 2.0f - 1.0f; qz = r2 * 2.0f - 1.0f;
-          l2 = dot_strict(qx, qy, qz, qx, qy, qz);
-        } else {
-          qx = __builtin_fmaf(r0, 2.0f, -1.0f); qy = __builtin_fmaf(r1, 2.0f, -1.0f); qz = __builtin_fmaf(r2, 2.0f, -1.0f);
-          l2 = dot_fast(qx, qy, qz, qx, qy, qz);
-        }
+        const float qx = rng_signed(s0), qy = rng_signed(s1), qz = rng_signed(s2);  // rand() * 2 - 1
+        const float l2 = STRICT ? dot_strict(qx, qy, qz, qx, qy, qz) : dot_fast(qx, qy, qz, qx, qy, qz);
         // STRICT: accept iff fl(fl(sqrt(l2))^2) < 1 (wgsl:284,306-309). fl(sqrt(.)) is monotone with
         // fl(sqrt(1)) = 1, and for l2 <= 1 - 2^-24 the rounded root is <= 1 - 2^-24, whose square
         // rounds below 1: the test equals l2 < 1 exactly.
@@ -456,17 +455,11 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
     for (uint32_t round = 1; round < a.reject_tries && __ballot(state == ST_NEED_DIR); ++round) {
       if (COUNT) c_wr++;
       if (state == ST_NEED_DIR) {
-        float r0, r1, r2;
-        RT_RAND(r0); RT_RAND(r1); RT_RAND(r2);
+        uint32_t s0, s1, s2;
+        RT_STEP(s0); RT_STEP(s1); RT_STEP(s2);
         if (COUNT) c_J++;
-        float qx, qy, qz, l2;
-        if (STRICT) {
-          qx = r0 * 2.0f - 1.0f; qy = r1 * 2.0f - 1.0f; qz = r2 * 2.0f - 1.0f;
-          l2 = dot_strict(qx, qy, qz, qx, qy, qz);
-        } else {
-          qx = __builtin_fmaf(r0, 2.0f, -1.0f); qy = __builtin_fmaf(r1, 2.0f, -1.0f); qz = __builtin_fmaf(r2, 2.0f, -1.0f);
-          l2 = dot_fast(qx, qy, qz, qx, qy, qz);
-        }
+        const float qx = rng_signed(s0), qy = rng_signed(s1), qz = rng_signed(s2);
+        const float l2 = STRICT ? dot_strict(qx, qy, qz, qx, qy, qz) : dot_fast(qx, qy, qz, qx, qy, qz);
         if (l2 < 1.0f) { gqx = qx; gqy = qy; gqz = qz; gl2 = l2; state = ST_GOT_DIR; }
       }
     }

@@ -23,11 +23,11 @@ def run(name, W, H, spp, scene, shade, math):
     parts = [("[G] draws", c["T"]), ("trace prelude", c["D"]), ("phase 1", c["H"]), ("phase 2", c["R"]), ("shade", c["M"])]
     other = life - sum(v for _, v in parts)
     print(f"{name} {'fast' if math else 'strict'}: {iters} wave-iterations, {life/iters:.0f} wave-cycles per iteration, "
-          f"shader clock {life / max(c['J'], 1) * 0.1:.2f} GHz, mean wave lifetime {c['J'] / 8192 * 1e-5:.2f} ms")
+          f"shader clock {life / max(c['J'], 1) * 0.1:.2f} GHz, mean wave lifetime {c['J'] / 6144 * 1e-5:.2f} ms")
     t0 = (~c["Sd"]) & 0xffffffffffffffff
     span = (c["N"] - t0) * 1e-5
     idle = rt.occupancy()["slots_trace"]
-    n = 8192
+    n = 6144  # 24 waves per CU x 256 CUs
     mean_start = (c["P"] / n - (t0 & 0xffffffff)) * 1e-5
     mean_end = (c["rand_calls"] / n - (t0 & 0xffffffff)) * 1e-5
     print(f"   launch span {span:.2f} ms; mean wave start +{mean_start:.2f} ms, mean wave end +{mean_end:.2f} ms; {idle} of {n} waves arrived to an empty queue")
