@@ -57,6 +57,17 @@ rt_ctx* rth_app_ctx(rth_app* app);            /* borrow the Raytracer's context 
 uint32_t rth_app_current_frame(rth_app* app);
 uint32_t rth_app_time_bits(rth_app* app);
 
+/* Checkpoint / resume. No counterpart in the reference: its accumulation lives in two wgpu
+ * textures and a render always restarts from frame 0 (src/resources/camera.rs:274-277). The file holds a
+ * 128-byte header (image size, flags, frame counter, time bits, camera, a hash of the scene) and the
+ * accumulation image as the device holds it; loading checks size, flags (the arithmetic mode may differ)
+ * and scene, restores App::time and App::camera, and the render continues bit-identically to one that was
+ * never interrupted. rth_checkpoint_info reads the header without a GPU:
+ * out9 = {width, height, flags, current_frame, frames_to_render, samples_per_pixel, time_bits, n_spheres, n_materials}. */
+int rth_app_save_checkpoint(rth_app* app, const char* path);
+int rth_app_load_checkpoint(rth_app* app, const char* path);
+int rth_checkpoint_info(const char* path, uint32_t out9[9], uint64_t* scene_hash, uint64_t* image_bytes);
+
 /* PNG writer. present != 0 applies the reference's screen pass: pow(c, 2.2)
  * (src/shaders/screen_shader.wgsl:36-39) then the sRGB surface encode (src/render_env.rs:48). */
 int rth_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height, int present);

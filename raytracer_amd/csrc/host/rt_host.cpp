@@ -91,6 +91,8 @@ uint64_t SeededRng::next_u64() {  // splitmix64
 float SeededRng::gen_f32() { return (float)(next_u64() >> 40) * (1.0f / 16777216.0f); }
 uint32_t SeededRng::gen_range(uint32_t n) { return (uint32_t)(((next_u64() >> 32) * (uint64_t)n) >> 32); }
 
+void Time::set_bits(uint32_t b) { std::memcpy(&time_, &b, 4); }
+
 uint32_t Time::bits() const {
   uint32_t b;
   std::memcpy(&b, &time_, 4);
@@ -248,7 +250,7 @@ void Raytracer::compute() { must(rt_compute(ctx_), "rt_compute"); }
 
 // ---------------------------------------------------------------------------------------------------
 App::App(int device, uint32_t width, uint32_t height, uint32_t flags, World w)
-    : camera(width, height), world(std::move(w)), ray_tracer(device, width, height, flags) {
+    : camera(width, height), world(std::move(w)), ray_tracer(device, width, height, flags), width_(width), height_(height), flags_(flags) {
   ray_tracer.bind_world(world);
   ray_tracer.write_camera(camera.to_raw());  // Camera::new -> scene_was_updated (camera.rs:74,283-288)
 }
@@ -345,6 +347,108 @@ bool write_png(const std::string& path, const uint8_t* rgba8, uint32_t width, ui
   if (!f) return false;
   const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
   return std::fclose(f) == 0 && ok;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Checkpoint file: 128-byte little-endian header, then the accumulation image exactly as the device holds
+// it (float4 or rgba8 per pixel).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr char kCkptMagic[8] = {'R', 'T', 'C', 'K', 'P', 'T', '0', '1'};
+struct CkptHeader {
+  char magic[8];
+  uint32_t width, height, flags, current_frame, frames_to_render, samples_per_pixel, time_bits, n_spheres, n_materials;
+  uint32_t reserved0;
+  uint64_t scene_hash, image_bytes;
+  float pos[3], look[3], z_near, z_far, fov, speed;
+  uint8_t pad[128 - 8 - 10 * 4 - 2 * 8 - 10 * 4];
+};
+static_assert(sizeof(CkptHeader) == 128, "checkpoint header is 128 bytes");
+
+uint64_t fnv1a(uint64_t h, const void* data, size_t n) {
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+uint64_t scene_hash(const World& w) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  h = fnv1a(h, w.spheres.data(), w.spheres.size() * sizeof(rt_sphere));
+  return fnv1a(h, w.materials.data(), w.materials.size() * sizeof(rt_material));
+}
+size_t image_bytes_of(uint32_t w, uint32_t h, uint32_t flags) { return (size_t)w * h * ((flags & RT_ACCUM_F32) ? 16u : 4u); }
+
+CkptHeader read_header(std::FILE* f, const std::string& path) {
+  CkptHeader hd;
+  if (std::fread(&hd, sizeof hd, 1, f) != 1) throw Error{RT_ERR_INVALID, "checkpoint " + path + ": shorter than its header"};
+  if (std::memcmp(hd.magic, kCkptMagic, 8) != 0) throw Error{RT_ERR_INVALID, "checkpoint " + path + ": bad magic"};
+  if (hd.width == 0 || hd.height == 0 || hd.width > 65536u || hd.height > 65536u || hd.image_bytes != image_bytes_of(hd.width, hd.height, hd.flags))
+    throw Error{RT_ERR_INVALID, "checkpoint " + path + ": inconsistent image size"};
+  return hd;
+}
+}  // namespace
+
+CheckpointInfo read_checkpoint_info(const std::string& path) {
+  std::FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) throw Error{RT_ERR_INVALID, "cannot open checkpoint " + path};
+  CkptHeader hd;
+  try { hd = read_header(f, path); } catch (...) { std::fclose(f); throw; }
+  std::fseek(f, 0, SEEK_END);
+  const long size = std::ftell(f);
+  std::fclose(f);
+  if (size < 0 || (uint64_t)size != sizeof(CkptHeader) + hd.image_bytes) throw Error{RT_ERR_INVALID, "checkpoint " + path + ": truncated image"};
+  return {hd.width, hd.height, hd.flags, hd.current_frame, hd.frames_to_render, hd.samples_per_pixel, hd.time_bits, hd.n_spheres, hd.n_materials,
+          hd.scene_hash, hd.image_bytes};
+}
+
+void App::save_checkpoint(const std::string& path) {
+  CkptHeader hd{};
+  std::memcpy(hd.magic, kCkptMagic, 8);
+  hd.width = width_; hd.height = height_; hd.flags = flags_;
+  hd.current_frame = camera.current_frame; hd.frames_to_render = camera.frames_to_render; hd.samples_per_pixel = camera.samples_per_pixel;
+  hd.time_bits = time.bits();
+  hd.n_spheres = (uint32_t)world.spheres.size(); hd.n_materials = (uint32_t)world.materials.size();
+  hd.scene_hash = scene_hash(world);
+  hd.image_bytes = image_bytes_of(width_, height_, flags_);
+  hd.pos[0] = camera.pos.x; hd.pos[1] = camera.pos.y; hd.pos[2] = camera.pos.z;
+  hd.look[0] = camera.look_direction.x; hd.look[1] = camera.look_direction.y; hd.look[2] = camera.look_direction.z;
+  hd.z_near = camera.z_near; hd.z_far = camera.z_far; hd.fov = camera.fov; hd.speed = camera.speed;
+  std::vector<uint8_t> img(hd.image_bytes);
+  const int rc = (flags_ & RT_ACCUM_F32) ? rt_read_accum_f32(ray_tracer.ctx(), img.data(), img.size())
+                                         : rt_read_rgba8(ray_tracer.ctx(), img.data(), img.size());
+  must(rc, "checkpoint read-back");
+  std::FILE* f = std::fopen(path.c_str(), "wb");
+  if (!f) throw Error{RT_ERR_INVALID, "cannot create checkpoint " + path};
+  const bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1 && std::fwrite(img.data(), 1, img.size(), f) == img.size();
+  if (std::fclose(f) != 0 || !ok) throw Error{RT_ERR_INVALID, "short write to checkpoint " + path};
+}
+
+void App::load_checkpoint(const std::string& path) {
+  std::FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) throw Error{RT_ERR_INVALID, "cannot open checkpoint " + path};
+  std::vector<uint8_t> img;
+  CkptHeader hd;
+  try {
+    hd = read_header(f, path);
+    // the accumulation format and the dispatch/shading flags decide what the image means; the arithmetic
+    // mode may differ (a strict render can be continued in fast mode and vice versa)
+    const uint32_t same = ~(uint32_t)RT_MATH_FAST;
+    if (hd.width != width_ || hd.height != height_ || (hd.flags & same) != (flags_ & same))
+      throw Error{RT_ERR_INVALID, "checkpoint " + path + ": image size or flags differ from this App"};
+    if (hd.n_spheres != world.spheres.size() || hd.n_materials != world.materials.size() || hd.scene_hash != scene_hash(world))
+      throw Error{RT_ERR_INVALID, "checkpoint " + path + ": was rendered from another scene"};
+    img.resize(hd.image_bytes);
+    if (std::fread(img.data(), 1, img.size(), f) != img.size()) throw Error{RT_ERR_INVALID, "checkpoint " + path + ": truncated image"};
+  } catch (...) { std::fclose(f); throw; }
+  std::fclose(f);
+  must(rt_write_image(ray_tracer.ctx(), img.data(), img.size()), "checkpoint upload");
+  camera.pos = {hd.pos[0], hd.pos[1], hd.pos[2]};
+  camera.look_direction = {hd.look[0], hd.look[1], hd.look[2]};
+  camera.z_near = hd.z_near; camera.z_far = hd.z_far; camera.fov = hd.fov; camera.speed = hd.speed;
+  camera.current_frame = hd.current_frame; camera.frames_to_render = hd.frames_to_render; camera.samples_per_pixel = hd.samples_per_pixel;
+  time.set_bits(hd.time_bits);
+  ray_tracer.write_camera(camera.to_raw());
+  ray_tracer.write_time(time.bits());
 }
 
 }  // namespace rt
@@ -480,6 +584,27 @@ int rth_app_redraw(rth_app* a, uint32_t n) {  // n x (App::update, App::render),
 }
 int rth_app_run(rth_app* a, uint32_t n) {  // same redraws, batched into one launch
   return guarded(a, [](rt::App& app, uint32_t k) { app.run(k); }, n);
+}
+int rth_app_save_checkpoint(rth_app* a, const char* path) {
+  if (!a || !path) { g_herr = "rth_app_save_checkpoint: null argument"; return RT_ERR_INVALID; }
+  try { a->app.save_checkpoint(path); } catch (const rt::Error& e) { g_herr = e.what; return e.code; }
+  return RT_OK;
+}
+int rth_app_load_checkpoint(rth_app* a, const char* path) {
+  if (!a || !path) { g_herr = "rth_app_load_checkpoint: null argument"; return RT_ERR_INVALID; }
+  try { a->app.load_checkpoint(path); } catch (const rt::Error& e) { g_herr = e.what; return e.code; }
+  return RT_OK;
+}
+int rth_checkpoint_info(const char* path, uint32_t out9[9], uint64_t* scene_hash, uint64_t* image_bytes) {
+  if (!path || !out9) { g_herr = "rth_checkpoint_info: null argument"; return RT_ERR_INVALID; }
+  try {
+    const rt::CheckpointInfo i = rt::read_checkpoint_info(path);
+    const uint32_t v[9] = {i.width, i.height, i.flags, i.current_frame, i.frames_to_render, i.samples_per_pixel, i.time_bits, i.n_spheres, i.n_materials};
+    std::memcpy(out9, v, sizeof v);
+    if (scene_hash) *scene_hash = i.scene_hash;
+    if (image_bytes) *image_bytes = i.image_bytes;
+  } catch (const rt::Error& e) { g_herr = e.what; return e.code; }
+  return RT_OK;
 }
 rt_ctx* rth_app_ctx(rth_app* a) { return a ? a->app.ray_tracer.ctx() : nullptr; }
 uint32_t rth_app_current_frame(rth_app* a) { return a ? a->app.camera.current_frame : 0; }

@@ -46,6 +46,7 @@ class Time {
   void add_delta(float delta) { time_ += delta; }  // time.rs:72-77
   float time() const { return time_; }
   uint32_t bits() const;
+  void set_bits(uint32_t b);  // checkpoint restore
  private:
   float time_;
 };
@@ -122,11 +123,28 @@ class App {
   void update();                   // app.rs:93-97
   void render();                   // app.rs:99-116 (compute pass only)
   void run(uint32_t redraws);      // `redraws` x (update, render), batched into one launch
+  // Checkpoint / resume (no counterpart in the reference, whose render restarts from frame 0):
+  // the accumulation image, the frame counter, the time and the camera, with a hash of the scene so a
+  // checkpoint cannot be resumed against other geometry. A resumed render continues bit-identically.
+  void save_checkpoint(const std::string& path);
+  void load_checkpoint(const std::string& path);
+  uint32_t width() const { return width_; }
+  uint32_t height() const { return height_; }
+  uint32_t flags() const { return flags_; }
   Time time;
   Camera camera;
   World world;
   Raytracer ray_tracer;
+ private:
+  uint32_t width_, height_, flags_;
 };
+
+// What a checkpoint file says about itself (readable without a GPU).
+struct CheckpointInfo {
+  uint32_t width, height, flags, current_frame, frames_to_render, samples_per_pixel, time_bits, n_spheres, n_materials;
+  uint64_t scene_hash, image_bytes;
+};
+CheckpointInfo read_checkpoint_info(const std::string& path);  // throws Error{RT_ERR_INVALID} on a malformed file
 
 // thrown by Raytracer/App on a non-zero ABI status (the reference panics via unwrap/expect)
 struct Error {

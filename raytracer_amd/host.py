@@ -34,6 +34,9 @@ SIGNATURES = {
     "rth_app_ctx": (_VP, [_VP]),
     "rth_app_current_frame": (C.c_uint32, [_VP]),
     "rth_app_time_bits": (C.c_uint32, [_VP]),
+    "rth_app_save_checkpoint": (C.c_int, [_VP, C.c_char_p]),
+    "rth_app_load_checkpoint": (C.c_int, [_VP, C.c_char_p]),
+    "rth_checkpoint_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rth_write_png": (C.c_int, [C.c_char_p, _VP, C.c_uint32, C.c_uint32, C.c_int]),
     "rth_last_error": (C.c_char_p, []),
 }
@@ -94,6 +97,17 @@ def time_table(n, start_bits=0):
     out = np.zeros(n, np.uint32)
     _check(load().rth_time_table(start_bits, n, _p(out)))
     return out
+
+
+def checkpoint_info(path):
+    """Header of a checkpoint file (no GPU needed)."""
+    v = (C.c_uint32 * 9)()
+    h, n = C.c_uint64(), C.c_uint64()
+    _check(load().rth_checkpoint_info(os.fsencode(path), v, C.byref(h), C.byref(n)))
+    keys = ("width", "height", "flags", "current_frame", "frames_to_render", "samples_per_pixel", "time_bits", "n_spheres", "n_materials")
+    d = dict(zip(keys, (int(x) for x in v)))
+    d["scene_hash"], d["image_bytes"] = int(h.value), int(n.value)
+    return d
 
 
 def write_png(path, rgba8, present=False):
@@ -166,6 +180,12 @@ class App:
         out = np.empty((self.height, self.width, 4), np.uint8)
         _abi.check(_abi.load().rt_read_rgba8(self._lib.rth_app_ctx(self._h), _p(out), out.nbytes))
         return out
+
+    def save_checkpoint(self, path):
+        _check(self._lib.rth_app_save_checkpoint(self._h, os.fsencode(path)))
+
+    def load_checkpoint(self, path):
+        _check(self._lib.rth_app_load_checkpoint(self._h, os.fsencode(path)))
 
     def close(self):
         if self._h:

@@ -401,3 +401,67 @@ def test_phase1_filter_edge_scenes(name):
     cam = scenes.camera_raw(64, 48, spp=3, frames=2, **camkw)
     for counters in (False, True):
         _strict_equals_oracle(R, 64, 48, 3, 2, O.ACCUM_F32, spheres, mats, cam, counters)
+
+
+@pytest.mark.parametrize("flags", [0, O.ACCUM_F32], ids=["rgba8", "f32"])
+def test_checkpoint_file_resumes_bit_identically_and_rejects_mismatches(flags, tmp_path):
+    """SURVEY 8f-4 through the host App: render 3 of 7 frames, save, load into a NEW App, finish; the image
+    equals the uninterrupted render's and the oracle's. A checkpoint of another scene / size is refused."""
+    R = _rt()
+    from raytracer_amd import host
+
+    W, H, spp, frames = 96, 64, 2, 7
+    spheres, mats = scenes.default_scene(1)
+    whole = host.App(W, H, flags, spheres, mats, spp=spp, frames=frames)
+    whole.run(frames)
+    want = whole.read_rgba8()
+    whole.close()
+
+    first = host.App(W, H, flags, spheres, mats, spp=spp, frames=frames)
+    first.redraw(3)
+    ck = str(tmp_path / "render.ckpt")
+    first.save_checkpoint(ck)
+    first.close()
+    info = host.checkpoint_info(ck)
+    assert info["current_frame"] == 3 and info["frames_to_render"] == frames and info["time_bits"] == int(O.time_bits_table(3)[2])
+
+    second = host.App(W, H, flags, spheres, mats, spp=1, frames=1)  # spp / frame count come from the file
+    second.load_checkpoint(ck)
+    assert second.current_frame == 3 and second.time_bits == info["time_bits"]
+    second.run(frames - 3)
+    got = second.read_rgba8()
+    second.close()
+    assert np.array_equal(got, want)
+    # the oracle on the host mirror's own camera bytes (its f32 matrices, not the tests' float64 derivation)
+    cam = host.camera_raw(W, H, spp=spp, frames=frames)
+    img2 = O.OracleImage(W, H, flags)
+    O.render(img2, spheres, mats, cam, 0, frames)
+    assert np.array_equal(got, img2.view_rgba8())
+
+    other_scene, other_mats = scenes.random_bunch(4, 3, 9)
+    for app in (host.App(W, H, flags, other_scene, other_mats, spp=spp, frames=frames),
+                host.App(W + 16, H, flags, spheres, mats, spp=spp, frames=frames),
+                host.App(W, H, flags ^ O.ACCUM_F32, spheres, mats, spp=spp, frames=frames)):
+        with pytest.raises(Exception):
+            app.load_checkpoint(ck)
+        app.close()
+    # the arithmetic mode may change across a resume
+    fast = host.App(W, H, flags | R.RT_MATH_FAST, spheres, mats, spp=spp, frames=frames)
+    fast.load_checkpoint(ck)
+    fast.run(frames - 3)
+    assert fast.current_frame == frames
+    fast.close()
+
+
+def test_headless_cli_checkpoint_round_trip(tmp_path):
+    """rt_headless --stop-after / --save-checkpoint / --resume: the resumed PNG equals the uninterrupted one."""
+    import os, subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "rt_headless")
+    base = [exe, "--width", "128", "--height", "64", "--spp", "2", "--frames", "6", "--scene", "checkers", "--seed", "3"]
+    a, b, ck = str(tmp_path / "a.png"), str(tmp_path / "b.png"), str(tmp_path / "r.ckpt")
+    subprocess.run(base + ["--out", a], check=True, timeout=120, capture_output=True)
+    subprocess.run(base + ["--stop-after", "2", "--save-checkpoint", ck], check=True, timeout=120, capture_output=True)
+    out = subprocess.run(base + ["--resume", ck, "--out", b], check=True, timeout=120, capture_output=True, text=True).stdout
+    assert "resumed" in out and "at frame 2 of 6" in out
+    assert open(a, "rb").read() == open(b, "rb").read()

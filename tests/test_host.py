@@ -143,3 +143,30 @@ def test_camera_controls_match_the_reference_rules():
     assert centre[0] > 0.05 and centre[2] < 0  # now looking to the right, still forward
     ref = scenes.camera_raw(640, 360, look=centre / np.linalg.norm(centre))
     assert np.abs(turned["pixel_to_world"] - ref["pixel_to_world"]).max() < 1e-5
+
+
+def _ckpt_bytes(width, height, flags, frame=3, image=None, magic=b"RTCKPT01"):
+    """A checkpoint file written by hand from the documented layout (include/rt_host.h)."""
+    import struct
+    n = width * height * (16 if flags & 1 else 4)
+    head = magic + struct.pack("<10I2Q10f", width, height, flags, frame, 8, 2, 0x3CF5C28F, 4, 3, 0, 0x1234, n,
+                               0, 0, 0, 0, 0, -1, 1.0, 1e5, 0.25, 0.05)
+    head += b"\0" * (128 - len(head))
+    return head + (image if image is not None else b"\x07" * n)
+
+
+def test_checkpoint_header_is_parsed_and_validated_without_a_gpu(tmp_path):
+    p = tmp_path / "a.ckpt"
+    p.write_bytes(_ckpt_bytes(32, 16, 1))
+    info = host.checkpoint_info(str(p))
+    assert (info["width"], info["height"], info["flags"], info["current_frame"]) == (32, 16, 1, 3)
+    assert info["time_bits"] == 0x3CF5C28F and info["scene_hash"] == 0x1234 and info["image_bytes"] == 32 * 16 * 16
+    for bad, why in [(_ckpt_bytes(32, 16, 1)[:100], "shorter"), (_ckpt_bytes(32, 16, 1, magic=b"NOTACKPT"), "magic"),
+                     (_ckpt_bytes(32, 16, 1)[:-5], "truncated"), (_ckpt_bytes(32, 16, 0, image=b"\0" * 7), "truncated")]:
+        p.write_bytes(bad)
+        try:
+            host.checkpoint_info(str(p))
+        except Exception as e:
+            assert why in str(e), (why, str(e))
+        else:
+            raise AssertionError(f"accepted a checkpoint that is {why}")
