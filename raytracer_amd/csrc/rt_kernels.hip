@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
   float gqx = 0, gqy = 0, gqz = 0, gl2 = 1.0f;                 // accepted point of random_in_unit_sphere, |q|^2
 
 #if RT_PROFILE_SECTIONS
-  unsigned long long prof_acc0 = 0, prof_acc1 = 0, prof_acc2 = 0, prof_acc3 = 0, prof_acc4 = 0, prof_iters = 0;
+  unsigned long long prof_acc0 = 0, prof_acc1 = 0, prof_acc2 = 0, prof_acc3 = 0, prof_acc4 = 0, prof_iters = 0, prof_p2_waves = 0, prof_p2_lanes = 0;
   const unsigned long long prof_start = __builtin_amdgcn_s_memtime(), prof_rstart = __builtin_amdgcn_s_memrealtime();
 #endif
   for (;;) {
@@ -529,6 +529,9 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         // (untamed rays take every sphere; the lowest cnt_pad - cnt bits are padding spheres)
         uint32_t cand = tame ? ~missbits : ((cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u));
         while (cand) {
+#if RT_PROFILE_SECTIONS
+          prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true));
+#endif
           const uint32_t lz = (uint32_t)__builtin_clz(cand);
           cand &= ~(0x80000000u >> lz);
           const uint32_t i = base + cnt_pad - 32u + lz;
@@ -645,12 +648,13 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
     const unsigned long long pv[8] = {prof_acc0, prof_acc1, prof_acc2, prof_acc3, prof_acc4, life, prof_iters, rlife};
     for (int i = 0; i < 8; ++i) atomicAdd(&a.counters[i], pv[i]);
     // launch shape: [8] = ~min start, [9] = max end, [10] = sum of starts, [11] = sum of ends (100 MHz ticks),
-    // [12] = waves that found the queue empty on arrival
+    // [12], [13] = lane- and wave-iterations of the phase-2 candidate loop
     atomicMax(&a.counters[8], ~prof_rstart);
     atomicMax(&a.counters[9], prof_rstart + rlife);
     atomicAdd(&a.counters[10], prof_rstart & 0xffffffffull);
     atomicAdd(&a.counters[11], (prof_rstart + rlife) & 0xffffffffull);
-    if (prof_iters <= 2) atomicAdd(&a.counters[12], 1ull);
+    atomicAdd(&a.counters[12], prof_p2_lanes);  // phase-2 loop: lane-iterations
+    atomicAdd(&a.counters[13], prof_p2_waves);  // phase-2 loop: wave-iterations
   }
 #endif
   if (COUNT) {

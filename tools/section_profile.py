@@ -26,11 +26,14 @@ def run(name, W, H, spp, scene, shade, math):
           f"shader clock {life / max(c['J'], 1) * 0.1:.2f} GHz, mean wave lifetime {c['J'] / 6144 * 1e-5:.2f} ms")
     t0 = (~c["Sd"]) & 0xffffffffffffffff
     span = (c["N"] - t0) * 1e-5
-    idle = rt.occupancy()["slots_trace"]
+    occ = rt.occupancy()
+    p2_lanes, p2_waves = occ["slots_trace"], occ["slots_reject"]
     n = 6144  # 24 waves per CU x 256 CUs
     mean_start = (c["P"] / n - (t0 & 0xffffffff)) * 1e-5
     mean_end = (c["rand_calls"] / n - (t0 & 0xffffffff)) * 1e-5
-    print(f"   launch span {span:.2f} ms; mean wave start +{mean_start:.2f} ms, mean wave end +{mean_end:.2f} ms; {idle} of {n} waves arrived to an empty queue")
+    print(f"   launch span {span:.2f} ms; mean wave start +{mean_start:.2f} ms, mean wave end +{mean_end:.2f} ms")
+    print(f"   phase-2 loop: {p2_waves / iters:.2f} wave-iterations per trace iteration, {p2_lanes / max(p2_waves, 1):.1f} of 64 lanes active, "
+          f"{p2_lanes / iters:.1f} candidates per wave and trace iteration")
     for k, v in parts + [("[E][F][A] + loop", other)]:
         print(f"   {k:18s} {100.0*v/life:5.1f} %   {v/iters:7.0f} cycles/iteration")
     rt.close()
