@@ -219,7 +219,8 @@ __device__ __forceinline__ uint32_t phase1_missbits(const_f32x16_ptr sph_p1, uin
 #define RT_PROF_END(i)
 #endif
 
-enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_READY = 2, ST_NEED_DIR = 3, ST_NEW_RAY = 4, ST_PATH_DONE = 5, ST_GOT_DIR = 6, ST_FRAME_END = 7 };
+// the parked states are 1 and 2 (one unsigned compare), everything runnable is >= ST_READY
+enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_FRAME_END = 2, ST_READY = 3, ST_NEED_DIR = 4, ST_NEW_RAY = 5, ST_PATH_DONE = 6, ST_GOT_DIR = 7 };
 
 // STRICT: arithmetic mode. COUNT: event counters for the roofline. CULL: phase 1 also drops spheres
 // behind the ray (strict, non-counting launches on small scenes; chosen by rt_launch_path_kernel).
@@ -284,9 +285,9 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
     // Both are rare per lane (once per spp samples) but, with 64 desynchronised lanes, would run at
     // 1/64 occupancy in every other iteration. Lanes park in FRAME_END / NEED_PIXEL until `batch_lanes`
     // of them wait, or nothing else is runnable in the wave.
-    const unsigned long long parked = __ballot(state == ST_FRAME_END || state == ST_NEED_PIXEL);
-    const unsigned long long runnable = __ballot(state != ST_FRAME_END && state != ST_NEED_PIXEL && state != ST_DEAD);
-    const bool service = parked && ((uint32_t)__popcll(parked) >= a.batch_lanes || !runnable);
+    const unsigned long long parked = __ballot(state - ST_NEED_PIXEL < 2u);  // NEED_PIXEL or FRAME_END
+    bool service = false;  // wave-uniform; most iterations have no parked lane and skip all of this
+    if (parked) service = (uint32_t)__popcll(parked) >= a.batch_lanes || !__ballot(state >= ST_READY);
     if (service && state == ST_FRAME_END) {
       // ---- end of this pixel's frame: color / spp (wgsl:122), store_color (wgsl:96-112) ----
       float p0, p1, p2;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         }
       }
     }
-    if (!__ballot(state != ST_DEAD)) break;  // every lane drained and the queue is empty
+    if (service && !__ballot(state != ST_DEAD)) break;  // every lane drained and the queue is empty (lanes die in [A] only)
 
     // ================= [G] random draws =================
     // Round 0 is shared: lanes starting a sample draw the two jitter numbers of get_random_ray
@@ -448,7 +449,8 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         // STRICT: accept iff fl(fl(sqrt(l2))^2) < 1 (wgsl:284,306-309). fl(sqrt(.)) is monotone with
         // fl(sqrt(1)) = 1, and for l2 <= 1 - 2^-24 the rounded root is <= 1 - 2^-24, whose square
         // rounds below 1: the test equals l2 < 1 exactly.
-        if (l2 < 1.0f) { gqx = qx; gqy = qy; gqz = qz; gl2 = l2; state = ST_GOT_DIR; }
+        gqx = qx; gqy = qy; gqz = qz; gl2 = l2;  // a rejected point is dead: no select needed
+        if (l2 < 1.0f) state = ST_GOT_DIR;
       }
     }
     if (COUNT) c_wr++;
@@ -460,7 +462,8 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         if (COUNT) c_J++;
         const float qx = rng_signed(s0), qy = rng_signed(s1), qz = rng_signed(s2);
         const float l2 = STRICT ? dot_strict(qx, qy, qz, qx, qy, qz) : dot_fast(qx, qy, qz, qx, qy, qz);
-        if (l2 < 1.0f) { gqx = qx; gqy = qy; gqz = qz; gl2 = l2; state = ST_GOT_DIR; }
+        gqx = qx; gqy = qy; gqz = qz; gl2 = l2;
+        if (l2 < 1.0f) state = ST_GOT_DIR;
       }
     }
     if (state == ST_GOT_DIR) {
