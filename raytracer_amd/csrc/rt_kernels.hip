@@ -224,6 +224,17 @@ enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_FRAME_END = 2, ST_READY = 3
 
 // STRICT: arithmetic mode. COUNT: event counters for the roofline. CULL: phase 1 also drops spheres
 // behind the ray (strict, non-counting launches on small scenes; chosen by rt_launch_path_kernel).
+// COLD KERNEL ARGUMENTS. Everything the per-pixel parts need (camera matrix, image geometry, buffers, frame
+// table) is read from the kernarg segment where it is used - behind a laundered pointer, so the compiler
+// cannot hoist the loads to the kernel entry and then keep ~40 scalar registers alive (and spilled into
+// VGPR lanes) across the hot loop. Only what the hit loop and the draws use is taken from `a` by value.
+typedef const __attribute__((address_space(4))) rt_kargs* rt_kargs_cptr;
+__device__ __forceinline__ rt_kargs_cptr cold_args() {
+  rt_kargs_cptr p = (rt_kargs_cptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 template <bool STRICT, bool COUNT, bool CULL>
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 6  // keeps the production variants at <= 80 VGPRs = 6 waves per SIMD (measured: C3 strict -2.7 %)
@@ -233,7 +244,6 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
   const bool checker = (a.flags & RT_SHADE_CHECKER) != 0;
   const bool accum_f32 = (a.flags & RT_ACCUM_F32) != 0;
   const bool combine_sum = (a.flags & RT_COMBINE_SUM) != 0;
-  const float* m = a.p2w;  // column-major
   const const_f32x16_ptr sph_p1 = (const_f32x16_ptr)(uintptr_t)a.sph_p1;
   const uint32_t n_spheres = a.n_spheres;
   const float spp_f = (float)a.spp;
@@ -287,12 +297,16 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
     // of them wait, or nothing else is runnable in the wave.
     const unsigned long long parked = __ballot(state - ST_NEED_PIXEL < 2u);  // NEED_PIXEL or FRAME_END
     bool service = false;  // wave-uniform; most iterations have no parked lane and skip all of this
-    if (parked) service = (uint32_t)__popcll(parked) >= a.batch_lanes || !__ballot(state >= ST_READY);
+    rt_kargs_cptr ca = (rt_kargs_cptr)0;
+    if (parked) {
+      ca = cold_args();
+      service = (uint32_t)__popcll(parked) >= ca->batch_lanes || !__ballot(state >= ST_READY);
+    }
     if (service && state == ST_FRAME_END) {
       // ---- end of this pixel's frame: color / spp (wgsl:122), store_color (wgsl:96-112) ----
       float p0, p1, p2;
-      if (a.inv_spp > 0.0f) {  // spp is a power of two: x / spp == x * (1/spp) exactly
-        p0 = sumx * a.inv_spp; p1 = sumy * a.inv_spp; p2 = sumz * a.inv_spp;
+      if (ca->inv_spp > 0.0f) {  // spp is a power of two: x / spp == x * (1/spp) exactly
+        p0 = sumx * ca->inv_spp; p1 = sumy * ca->inv_spp; p2 = sumz * ca->inv_spp;
       } else {
         p0 = sumx / spp_f; p1 = sumy / spp_f; p2 = sumz / spp_f;
       }
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         acc0 = acc0 + p0; acc1 = acc1 + p1; acc2 = acc2 + p2; acc3 = acc3 + p3;
       } else {
         // cw = f32(frame) / f32(frame + 1) (wgsl:108-109), computed on the host with the same IEEE division
-        const float cw = a.frame_table ? as_f32(a.frame_table[k].y) : a.cw0;
+        const float cw = ca->frame_table ? as_f32(ca->frame_table[k].y) : ca->cw0;
         const float rw = 1.0f - cw;
         acc0 = p0 * rw + acc0 * cw; acc1 = p1 * rw + acc1 * cw; acc2 = p2 * rw + acc2 * cw; acc3 = p3 * rw + acc3 * cw;
       }
@@ -313,19 +327,19 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         acc0 = unorm8_to_f32(q0); acc1 = unorm8_to_f32(q1); acc2 = unorm8_to_f32(q2); acc3 = unorm8_to_f32(q3);
       }
       k++;
-      if (k == a.n_frames) {
+      if (k == ca->n_frames) {
         // ---- pixel finished: write once, then ask for the next pixel ----
         if (accum_f32) {
           f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
-          reinterpret_cast<f32x4*>(a.accum)[pix] = o;
+          reinterpret_cast<f32x4*>(ca->accum)[pix] = o;
         } else {
-          reinterpret_cast<uint32_t*>(a.accum)[pix] = q8;
+          reinterpret_cast<uint32_t*>(ca->accum)[pix] = q8;
         }
-        if (a.rng_out) a.rng_out[pix] = rng;
-        if (a.tile_cost) atomicAdd(&a.tile_cost[my_tile], iters);
+        if (ca->rng_out) ca->rng_out[pix] = rng;
+        if (ca->tile_cost) atomicAdd(&ca->tile_cost[my_tile], iters);
         state = ST_NEED_PIXEL;
       } else {
-        rng = seed_xy ^ a.frame_table[k].x;
+        rng = seed_xy ^ ca->frame_table[k].x;
         rng = rng_step(rng);
         if (COUNT) c_rand++;
         sample = 0; sumx = sumy = sumz = 0.0f;
@@ -351,9 +365,9 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
       if (n_need > avail) {
         uint32_t base = 0xffffffffu;
         if (more) {
-          if (lane == 0) base = atomicAdd(a.queue, 1u);  // all 64 lanes are active here (uniform loop)
+          if (lane == 0) base = atomicAdd(ca->queue, 1u);  // all 64 lanes are active here (uniform loop)
           base = __builtin_amdgcn_readfirstlane(base);
-          if (base >= a.my_tiles) { more = false; base = 0xffffffffu; }
+          if (base >= ca->my_tiles) { more = false; base = 0xffffffffu; }
         }
         if (base != 0xffffffffu) {
           // ---- stage tile `base`: all 64 lanes compute the per-pixel constants of its 64 pixels at full
@@ -361,19 +375,20 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
           // wgsl:258-259) into LDS; lanes pick their record up when they are handed the pixel.
           // tiles are handed out in the order of the previous launch's measured cost, dearest first, so
           // the launch ends on cheap pixels (results do not depend on the order)
-          q_tile_new = a.tile_order ? a.tile_order[base] : base;
-          const uint32_t tile = q_tile_new * a.world + a.rank;
-          const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+          q_tile_new = ca->tile_order ? ca->tile_order[base] : base;
+          const uint32_t tile = q_tile_new * ca->world + ca->rank;
+          const uint32_t tx = tile % ca->tiles_x, ty = tile / ca->tiles_x;
           const uint32_t pu = tx * 8u + (lane & 7u), pv = ty * 8u + (lane >> 3);
-          const float vx = (float)pu, vy = (float)(a.height - pv);
-          const float wx = (float)(pu + 1u), wy = (float)(a.height - (pv + 1u));
+          const float vx = (float)pu, vy = (float)(ca->height - pv);
+          const float wx = (float)(pu + 1u), wy = (float)(ca->height - (pv + 1u));
+          const __attribute__((address_space(4))) float* m = ca->p2w;  // column-major
           const float cx = ((m[0] * vx + m[4] * vy) + m[8] * 0.0f) + m[12] * 1.0f;
           const float cy = ((m[1] * vx + m[5] * vy) + m[9] * 0.0f) + m[13] * 1.0f;
           const float cz = ((m[2] * vx + m[6] * vy) + m[10] * 0.0f) + m[14] * 1.0f;
           const float nx = ((m[0] * wx + m[4] * wy) + m[8] * 0.0f) + m[12] * 1.0f;
           const float ny = ((m[1] * wx + m[5] * wy) + m[9] * 0.0f) + m[13] * 1.0f;
           const float nz = ((m[2] * wx + m[6] * wy) + m[10] * 0.0f) + m[14] * 1.0f;
-          const bool inside = pu < a.cov_w && pv < a.cov_h;  // false only on ragged edges in RT_DISPATCH_FULL
+          const bool inside = pu < ca->cov_w && pv < ca->cov_h;  // false only on ragged edges in RT_DISPATCH_FULL
           f32x4 w0, w1;
           w0.x = cx; w0.y = cy; w0.z = cz; w0.w = as_f32(inside ? (pv << 16 | pu) : 0xffffffffu);
           w1.x = nx - cx; w1.y = ny - cy; w1.z = nz - cz; w1.w = as_f32(rng_seed_pixel(pu, pv));
@@ -403,18 +418,18 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
           pcx = rec0.x; pcy = rec0.y; pcz = rec0.z;
           pdx = rec1.x; pdy = rec1.y; pdz = rec1.z;
           const uint32_t uvp = as_u32(rec0.w);
-          pix = (size_t)(uvp >> 16) * a.width + (uvp & 0xffffu);
+          pix = (size_t)(uvp >> 16) * ca->width + (uvp & 0xffffu);
           seed_xy = as_u32(rec1.w);
           if (accum_f32) {
-            const f32x4 c = reinterpret_cast<const f32x4*>(a.accum)[pix];
+            const f32x4 c = reinterpret_cast<const f32x4*>(ca->accum)[pix];
             acc0 = c.x; acc1 = c.y; acc2 = c.z; acc3 = c.w;
           } else {
-            const uint32_t q = reinterpret_cast<const uint32_t*>(a.accum)[pix];
+            const uint32_t q = reinterpret_cast<const uint32_t*>(ca->accum)[pix];
             acc0 = unorm8_to_f32(q & 255u); acc1 = unorm8_to_f32((q >> 8) & 255u);
             acc2 = unorm8_to_f32((q >> 16) & 255u); acc3 = unorm8_to_f32(q >> 24);
           }
           k = 0;
-          rng = seed_xy ^ (a.frame_table ? a.frame_table[0].x : a.seed_t0);
+          rng = seed_xy ^ (ca->frame_table ? ca->frame_table[0].x : ca->seed_t0);
           rng = rng_step(rng);  // initialize_rng's discarded rand() (wgsl:262)
           if (COUNT) c_rand++;
           sample = 0; sumx = sumy = sumz = 0.0f;
@@ -644,29 +659,30 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
     }
   }
 
+  const rt_kargs_cptr ca = cold_args();
 #if RT_PROFILE_SECTIONS
   if (lane == 0) {
     const unsigned long long life = __builtin_amdgcn_s_memtime() - prof_start;
     const unsigned long long rlife = __builtin_amdgcn_s_memrealtime() - prof_rstart;  // 100 MHz
     const unsigned long long pv[8] = {prof_acc0, prof_acc1, prof_acc2, prof_acc3, prof_acc4, life, prof_iters, rlife};
-    for (int i = 0; i < 8; ++i) atomicAdd(&a.counters[i], pv[i]);
+    for (int i = 0; i < 8; ++i) atomicAdd(&ca->counters[i], pv[i]);
     // launch shape: [8] = ~min start, [9] = max end, [10] = sum of starts, [11] = sum of ends (100 MHz ticks),
     // [12], [13] = lane- and wave-iterations of the phase-2 candidate loop
-    atomicMax(&a.counters[8], ~prof_rstart);
-    atomicMax(&a.counters[9], prof_rstart + rlife);
-    atomicAdd(&a.counters[10], prof_rstart & 0xffffffffull);
-    atomicAdd(&a.counters[11], (prof_rstart + rlife) & 0xffffffffull);
-    atomicAdd(&a.counters[12], prof_p2_lanes);  // phase-2 loop: lane-iterations
-    atomicAdd(&a.counters[13], prof_p2_waves);  // phase-2 loop: wave-iterations
+    atomicMax(&ca->counters[8], ~prof_rstart);
+    atomicMax(&ca->counters[9], prof_rstart + rlife);
+    atomicAdd(&ca->counters[10], prof_rstart & 0xffffffffull);
+    atomicAdd(&ca->counters[11], (prof_rstart + rlife) & 0xffffffffull);
+    atomicAdd(&ca->counters[12], prof_p2_lanes);  // phase-2 loop: lane-iterations
+    atomicAdd(&ca->counters[13], prof_p2_waves);  // phase-2 loop: wave-iterations
   }
 #endif
   if (COUNT) {
     const uint32_t vals[12] = {c_T, c_D, c_H, c_R, c_M, c_S, c_Sm, c_J, c_Sd, c_N, c_P, c_rand};
 #pragma unroll
-    for (int i = 0; i < 12; ++i) atomicAdd(&a.counters[i], (unsigned long long)vals[i]);
+    for (int i = 0; i < 12; ++i) atomicAdd(&ca->counters[i], (unsigned long long)vals[i]);
     if (lane == 0) {
-      atomicAdd(&a.counters[12], 64ull * c_wt);
-      atomicAdd(&a.counters[13], 64ull * c_wr);
+      atomicAdd(&ca->counters[12], 64ull * c_wt);
+      atomicAdd(&ca->counters[13], 64ull * c_wr);
     }
   }
 }
