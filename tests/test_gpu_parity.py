@@ -465,3 +465,41 @@ def test_headless_cli_checkpoint_round_trip(tmp_path):
     out = subprocess.run(base + ["--resume", ck, "--out", b], check=True, timeout=120, capture_output=True, text=True).stdout
     assert "resumed" in out and "at frame 2 of 6" in out
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def _fuzz_scene(rs):
+    """Random scenes that lean on the phase-1 filter's assumptions: mixed magnitudes, overlaps, a camera that
+    may sit inside a sphere or far from the origin, zero and negative radii."""
+    n = int(rs.choice([1, 2, 3, 4, 6, 9, 17, 40]))
+    scale = float(rs.choice([0.05, 1.0, 1.0, 30.0, 3000.0]))
+    centers = (rs.random_sample((n, 3)) * 2 - 1) * scale * np.array([1.0, 1.0, 1.0]) + np.array([0, 0, -1.5 * scale])
+    radii = rs.random_sample(n) * scale * float(rs.choice([0.05, 0.5, 2.0]))
+    kind = rs.randint(0, 6)
+    if kind == 0:
+        radii[rs.randint(n)] = 0.0
+    elif kind == 1:
+        radii[rs.randint(n)] *= -1.0          # the shader never checks the sign: r*r and 1/r take it as is
+    elif kind == 2 and n > 1:
+        centers[1] = centers[0]; radii[1] = radii[0]  # coincident spheres: equal roots, first index wins
+    elif kind == 3:
+        radii[rs.randint(n)] = 2.0 ** int(rs.randint(-6, 6))  # power-of-two radius: the multiply path
+    mats = scenes.make_materials(rs.random_sample((3, 4)).astype(np.float32))
+    spheres = scenes.make_spheres(centers.astype(np.float32), radii.astype(np.float32), rs.randint(0, 3, size=n))
+    pos = tuple(((rs.random_sample(3) * 2 - 1) * scale * float(rs.choice([0.0, 0.3, 1.5]))).tolist())
+    look = centers.mean(axis=0) - np.asarray(pos) + (rs.random_sample(3) * 2 - 1) * 0.2 * scale  # towards the scene
+    if not np.isfinite(look).all() or np.linalg.norm(look) < 1e-6 * scale or abs(look[0]) + abs(look[2]) < 1e-6 * scale:
+        look = np.array([0.1, 0.0, -1.0])
+    return spheres, mats, dict(pos=pos, look=tuple(look.tolist()), fov=float(rs.choice([0.1, 0.25, 0.45])))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzzed_scenes_stay_bit_exact(seed):
+    """Strict mode against the oracle on random scenes and cameras, counting and production kernel variants,
+    head and checker shading."""
+    R = _rt()
+    rs = np.random.RandomState(1000 + seed)
+    spheres, mats, camkw = _fuzz_scene(rs)
+    flags = O.ACCUM_F32 | (O.SHADE_CHECKER if seed % 3 == 0 else 0)
+    cam = scenes.camera_raw(48, 32, spp=3, frames=2, **camkw)
+    for counters in (False, True):
+        _strict_equals_oracle(R, 48, 32, 3, 2, flags, spheres, mats, cam, counters)
