@@ -15,9 +15,9 @@
 //  * TWO-PHASE HIT LOOP. Phase 1 walks the spheres with a wave-uniform index: per-sphere constants
 //    arrive by scalar loads and are used straight from SGPR pairs, two spheres per v_pk_fma_f32,
 //    5-6 VALU instructions per sphere, no branch; the sign bit of a conservative discriminant is
-//    shifted into a per-lane 32-sphere bitmask (v_alignbit). Phase 2 lets every lane walk ITS OWN candidate bits (gathered
-//    loads), so the expensive root code (sqrt, divisions) runs at full lane occupancy instead of
-//    once per sphere that any lane of the wave might hit.
+//    shifted into a per-lane 32-sphere bitmask (v_alignbit). Phase 2 lets every lane walk ITS OWN
+//    candidate bits (gathered loads), so the expensive root code (sqrt, divisions) runs once per
+//    candidate of a lane instead of once per sphere that any lane of the wave might hit.
 //  * BOUNDED REJECTION SAMPLING. random_in_unit_sphere (p = pi/6) runs at most `reject_tries`
 //    rounds per iteration; lanes still without a direction sit out one trace instead of making 63
 //    lanes wait for the unluckiest one.
