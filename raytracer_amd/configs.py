@@ -13,7 +13,7 @@ CONFIGS = {
     "C2": (1920, 1080, 16, 256, ("default", 1), _abi.RT_ACCUM_RGBA8,
            "default scene, 1920x1080, 16 spp x 256 frames, one GPU"),
     "C3": (3840, 2160, 64, 8, ("bunch", 20, 3, 3), _abi.RT_ACCUM_F32 | _abi.RT_SHADE_CHECKER,
-           "glowing-checkers reconstruction, random_bunch(20), 3840x2160, 64 spp, image tiles across GPUs"),
+           "glowing-checkers reconstruction, random_bunch(20), 3840x2160, 64 spp"),
     "C4": (1920, 1080, 4, 16, ("bunch", 1024, 16, 4), _abi.RT_ACCUM_RGBA8,
            "random_bunch(1024), 16 materials, 1920x1080, 4 spp x 16 frames"),
     "C5": (7680, 4320, 1, 1024, ("default", 1), _abi.RT_ACCUM_F32 | _abi.RT_COMBINE_SUM,
