@@ -80,3 +80,30 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or fn == "Makefile":
                 text = open(os.path.join(base, fn), errors="replace").read()
                 assert "oracle_lib" not in text and "rt_oracle" not in text and "librt_oracle" not in text, fn
+
+
+def test_headers_are_plain_c_and_a_c_caller_links(tmp_path):
+    """include/*.h is the drop-in boundary: it must parse as strict C99 (what cgo / bindgen / a C host sees) and a
+    C program that calls it must link against the shared libraries (no compute call is made without a GPU)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    src = tmp_path / "caller.c"
+    src.write_text(
+        '#include "rt_hip.h"\n#include "rt_host.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "  rt_ctx* ctx = 0;\n"
+        "  /* width 0 is rejected before any device is touched */\n"
+        "  int rc = rt_create(&ctx, 0, 0u, 0u, RT_ACCUM_F32 | RT_MATH_STRICT);\n"
+        "  uint32_t bits[3];\n"
+        "  int rc2 = rth_time_table(0u, 3u, bits);\n"
+        '  printf("%d %d %08x %s\\n", rc, rc2, (unsigned)bits[2], rt_version());\n'
+        "  return (rc == RT_ERR_INVALID && rc2 == RT_OK && ctx == 0) ? 0 : 1;\n}\n")
+    exe = tmp_path / "caller"
+    lib = os.path.join(root, "raytracer_amd")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", f"-I{inc}", str(src), "-o", str(exe),
+                    f"-L{lib}", "-lrt_host", "-lrt_hip", f"-Wl,-rpath,{lib}"], check=True, capture_output=True, timeout=120)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "3cf5c28f" in out.stdout  # 3 x 0.01f accumulated (time.rs:72-77)
