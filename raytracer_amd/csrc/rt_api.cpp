@@ -72,6 +72,10 @@ struct rt_ctx {
   bool time_pending = false;
   // RGBA8 view of a float image
   void* quant = nullptr;
+  // staged launches: frame colours of a batch (n_frames x width x height float4)
+  rt_f32x4* staging = nullptr;
+  size_t staging_bytes = 0;
+  int use_staging = 1;        // env RT_STAGED_FRAMES=0 keeps batched launches pixel-sequential
   // per-launch timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -98,6 +102,9 @@ void covered(const rt_ctx* c, uint32_t* cov_w, uint32_t* cov_h) {
 }
 
 constexpr uint32_t RT_ORDER_REFRESH = 32;  // launches between two measurements of the per-tile cost
+constexpr uint64_t RT_STAGE_BELOW = 32;    // batches are staged per frame when a rank has fewer tiles per wave than this
+constexpr uint32_t RT_STAGE_MIN_SPP = 4;   // below that a (tile, frame) unit is too little work for its hand-out (C1: 1 spp got slower)
+constexpr size_t RT_STAGE_MAX_BYTES = (size_t)4 << 30;  // largest staging buffer a context allocates
 
 float frame_cw(uint32_t frame) {
   // combine_pixel_cache_color (wgsl:107-109): cw = f32(frame) / f32(frame + 1), one IEEE division
@@ -149,7 +156,26 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // Persistent launch: enough single-wave workgroups to fill every SIMD, never more than tiles.
   const uint32_t wpc = ctx->waves_per_cu > 0 ? (uint32_t)ctx->waves_per_cu : 24u;  // 6 waves per SIMD are resident (<= 80 VGPRs)
   const uint64_t resident = (uint64_t)ctx->compute_units * wpc;
-  const uint32_t n_waves = (uint32_t)(resident < my_tiles ? resident : my_tiles);
+  // STAGED LAUNCH (batches only): a pixel is sequential, so with few tiles per wave the launch would end on
+  // the waves that drew the dearest pixels - for all n_frames of them. When a rank has fewer than
+  // RT_STAGE_BELOW tiles per wave (and at least RT_STAGE_MIN_SPP samples per pixel), the unit of work becomes (tile, frame): the frames' colours go to a
+  // staging buffer and a second kernel folds them into the image in order (same arithmetic, bit-identical).
+  a.n_units = my_tiles;
+  const size_t stage_bytes = (size_t)n_frames * ctx->width * ctx->height * sizeof(rt_f32x4);
+  if (ctx->use_staging && n_frames > 1 && time_table_dev && a.spp >= RT_STAGE_MIN_SPP && (uint64_t)my_tiles < RT_STAGE_BELOW * resident &&
+      stage_bytes <= RT_STAGE_MAX_BYTES && (uint64_t)my_tiles * n_frames < 0xffffffffull / 64u) {
+    if (ctx->staging_bytes < stage_bytes) {
+      RT_HIP(hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->staging);
+      ctx->staging = nullptr;
+      ctx->staging_bytes = 0;
+      RT_HIP(hipMalloc((void**)&ctx->staging, stage_bytes));
+      ctx->staging_bytes = stage_bytes;
+    }
+    a.staging = ctx->staging;
+    a.n_units = my_tiles * n_frames;
+  }
+  const uint32_t n_waves = (uint32_t)(resident < a.n_units ? resident : a.n_units);
   // host-side shape check before the launch: every tile index a block can form is < n_tiles or
   // rejected by the kernel's own guard; every pixel index is < width*height by construction of cov_*
   if (a.cov_w > a.width || a.cov_h > a.height) return fail(RT_ERR_INVALID, "covered area exceeds the image");
@@ -194,6 +220,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   }
   RT_HIP(hipMemsetAsync(ctx->queue, 0, sizeof(uint32_t), ctx->stream));
   RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, ctx->stream));
+  if (a.staging) RT_HIP(rt_launch_combine_frames(a, ctx->stream));
   if (ctx->timing) RT_HIP(hipEventRecord(e1, ctx->stream));
   if (measure) {
     RT_HIP(rt_launch_tile_order(ctx->tile_cost, ctx->tile_order, my_tiles, ctx->stream));
@@ -245,6 +272,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e2 = std::getenv("RT_REJECT_TRIES")) c->reject_tries = std::atoi(e2);
   if (const char* e3 = std::getenv("RT_BATCH_LANES")) c->batch_lanes = std::atoi(e3);
   if (const char* e4 = std::getenv("RT_TILE_ORDER")) c->use_order = std::atoi(e4);
+  if (const char* e5 = std::getenv("RT_STAGED_FRAMES")) c->use_staging = std::atoi(e5);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
   if (e == hipSuccess) {
     c->stream = c->own_stream;
@@ -282,6 +310,7 @@ void rt_destroy(rt_ctx* c) {
   (void)hipFree(c->sph_col);
   (void)hipFree(c->time_dev);
   (void)hipFree(c->quant);
+  (void)hipFree(c->staging);
   if (c->time_host) (void)hipHostFree(c->time_host);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;

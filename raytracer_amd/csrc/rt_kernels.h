@@ -22,6 +22,7 @@ struct rt_kargs {
   uint32_t tiles_x, n_tiles;  // 8x8 tiles over the covered area
   uint32_t rank, world;     // tile t belongs to this launch iff t % world == rank
   uint32_t my_tiles;        // number of tiles of this rank: tile = j * world + rank, j < my_tiles
+  uint32_t n_units;         // queue length: my_tiles, or my_tiles * n_frames in a staged launch
   uint32_t reject_tries;    // rejection-sampling rounds per loop iteration (>= 1)
   uint32_t spp;
   uint32_t first_frame, n_frames;
@@ -38,6 +39,7 @@ struct rt_kargs {
   const rt_f32x4* sph_shade;
   const rt_f32x4* sph_col;
   void* accum;                   // RGBA8: uint32 per pixel; F32: float4 per pixel
+  rt_f32x4* staging;             // staged launch: n_frames x width x height frame colours, else null
   uint32_t* rng_out;             // optional
   unsigned long long* counters;  // 14 x u64, COUNT variants only
   uint32_t* queue;               // tile queue head, zeroed on the stream before every launch
@@ -47,5 +49,7 @@ struct rt_kargs {
 
 // n_waves persistent single-wave workgroups pull tiles from a.queue until a.my_tiles are handed out
 hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, hipStream_t stream);
+// folds the staged frame colours into the accumulation image, in frame order, for the pixels of this rank's tiles
+hipError_t rt_launch_combine_frames(const rt_kargs& a, hipStream_t stream);
 hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t n, hipStream_t stream);
 hipError_t rt_launch_quantize(const void* src_f32x4, void* dst_rgba8, size_t n_pixels, hipStream_t stream);

@@ -219,6 +219,28 @@ __device__ __forceinline__ uint32_t phase1_missbits(const_f32x16_ptr sph_p1, uin
 #define RT_PROF_END(i)
 #endif
 
+// One frame of store_color / combine_pixel_cache_color (wgsl:96-112) on the accumulation pixel `acc`, shared
+// by the path kernel (pixel-sequential launches) and rt_combine_frames_kernel (staged launches) so that both
+// perform the same operations in the same order. p = this frame's colour (already divided by spp), cw as
+// in wgsl:108-109. Returns the rgba8unorm word (RT_ACCUM_RGBA8) after re-quantising acc.
+__device__ __forceinline__ uint32_t combine_frame(float& acc0, float& acc1, float& acc2, float& acc3, float p0, float p1, float p2,
+                                                  float cw, bool combine_sum, bool accum_f32) {
+  const float p3 = 1.0f;
+  if (combine_sum) {
+    acc0 = acc0 + p0; acc1 = acc1 + p1; acc2 = acc2 + p2; acc3 = acc3 + p3;
+  } else {
+    const float rw = 1.0f - cw;
+    acc0 = p0 * rw + acc0 * cw; acc1 = p1 * rw + acc1 * cw; acc2 = p2 * rw + acc2 * cw; acc3 = p3 * rw + acc3 * cw;
+  }
+  uint32_t q8 = 0;
+  if (!accum_f32) {  // the reference re-quantises to rgba8unorm every frame (raytracing.rs:30,47)
+    const uint32_t q0 = unorm8(acc0), q1 = unorm8(acc1), q2 = unorm8(acc2), q3 = unorm8(acc3);
+    q8 = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+    acc0 = unorm8_to_f32(q0); acc1 = unorm8_to_f32(q1); acc2 = unorm8_to_f32(q2); acc3 = unorm8_to_f32(q3);
+  }
+  return q8;
+}
+
 // the parked states are 1 and 2 (one unsigned compare), everything runnable is >= ST_READY
 enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_FRAME_END = 2, ST_READY = 3, ST_NEED_DIR = 4, ST_NEW_RAY = 5, ST_PATH_DONE = 6, ST_GOT_DIR = 7 };
 
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
   uint32_t seed_xy = 0;      // pixel part of the RNG seed
   uint32_t my_tile = 0;      // index (in this rank's tile list) of the tile the pixel belongs to
   uint32_t iters = 0;        // trace iterations spent on the current pixel (cost feedback for the tile order)
-  uint32_t q_tile = 0, q_tile_new = 0;  // wave-uniform: tile being handed out
+  uint32_t q_tile = 0, q_tile_new = 0, q_frame = 0;  // wave-uniform: tile (and, staged, frame) being handed out
   float pcx = 0, pcy = 0, pcz = 0, pdx = 0, pdy = 0, pdz = 0;  // pixel_center, pixel_delta
   float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;                // accumulation pixel
   uint32_t k = 0, rng = 0, sample = 0, depth = 0;
@@ -310,34 +332,35 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
       } else {
         p0 = sumx / spp_f; p1 = sumy / spp_f; p2 = sumz / spp_f;
       }
-      const float p3 = 1.0f;
       if (COUNT) c_P++;
-      if (combine_sum) {
-        acc0 = acc0 + p0; acc1 = acc1 + p1; acc2 = acc2 + p2; acc3 = acc3 + p3;
+      bool done;          // nothing left to do for this lane's unit of work
+      bool last_frame;    // the RNG state is the one the capture hook wants
+      if (ca->staging) {
+        // STAGED LAUNCH: the unit of work is (pixel, frame k). The frame's colour goes to the staging buffer;
+        // rt_combine_frames_kernel folds the frames into the image in order afterwards.
+        f32x4 o; o.x = p0; o.y = p1; o.z = p2; o.w = 1.0f;
+        ca->staging[(size_t)k * ((size_t)ca->width * ca->height) + pix] = o;
+        done = true;
+        last_frame = k + 1u == ca->n_frames;
       } else {
         // cw = f32(frame) / f32(frame + 1) (wgsl:108-109), computed on the host with the same IEEE division
         const float cw = ca->frame_table ? as_f32(ca->frame_table[k].y) : ca->cw0;
-        const float rw = 1.0f - cw;
-        acc0 = p0 * rw + acc0 * cw; acc1 = p1 * rw + acc1 * cw; acc2 = p2 * rw + acc2 * cw; acc3 = p3 * rw + acc3 * cw;
-      }
-      uint32_t q8 = 0;
-      if (!accum_f32) {  // the reference re-quantises to rgba8unorm every frame (raytracing.rs:30,47)
-        const uint32_t q0 = unorm8(acc0), q1 = unorm8(acc1), q2 = unorm8(acc2), q3 = unorm8(acc3);
-        q8 = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
-        acc0 = unorm8_to_f32(q0); acc1 = unorm8_to_f32(q1); acc2 = unorm8_to_f32(q2); acc3 = unorm8_to_f32(q3);
-      }
-      k++;
-      if (k == ca->n_frames) {
-        // ---- pixel finished: write once, then ask for the next pixel ----
-        if (accum_f32) {
-          f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
-          reinterpret_cast<f32x4*>(ca->accum)[pix] = o;
-        } else {
-          reinterpret_cast<uint32_t*>(ca->accum)[pix] = q8;
+        const uint32_t q8 = combine_frame(acc0, acc1, acc2, acc3, p0, p1, p2, cw, combine_sum, accum_f32);
+        k++;
+        done = last_frame = k == ca->n_frames;
+        if (done) {  // pixel finished: written once per launch
+          if (accum_f32) {
+            f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
+            reinterpret_cast<f32x4*>(ca->accum)[pix] = o;
+          } else {
+            reinterpret_cast<uint32_t*>(ca->accum)[pix] = q8;
+          }
         }
-        if (ca->rng_out) ca->rng_out[pix] = rng;
+      }
+      if (done) {
+        if (ca->rng_out && last_frame) ca->rng_out[pix] = rng;
         if (ca->tile_cost) atomicAdd(&ca->tile_cost[my_tile], iters);
-        state = ST_NEED_PIXEL;
+        state = ST_NEED_PIXEL;  // ask for the next pixel
       } else {
         rng = seed_xy ^ ca->frame_table[k].x;
         rng = rng_step(rng);
@@ -359,7 +382,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
       if (wants && my < avail) {  // a pixel of the tile already staged in LDS
         const uint32_t w = (q_cur + my) & 63u;
         rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
-        my_tile = q_tile;
+        my_tile = q_tile; k = q_frame;
         got = true;
       }
       if (n_need > avail) {
@@ -367,7 +390,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         if (more) {
           if (lane == 0) base = atomicAdd(ca->queue, 1u);  // all 64 lanes are active here (uniform loop)
           base = __builtin_amdgcn_readfirstlane(base);
-          if (base >= ca->my_tiles) { more = false; base = 0xffffffffu; }
+          if (base >= ca->n_units) { more = false; base = 0xffffffffu; }
         }
         if (base != 0xffffffffu) {
           // ---- stage tile `base`: all 64 lanes compute the per-pixel constants of its 64 pixels at full
@@ -375,7 +398,10 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
           // wgsl:258-259) into LDS; lanes pick their record up when they are handed the pixel.
           // tiles are handed out in the order of the previous launch's measured cost, dearest first, so
           // the launch ends on cheap pixels (results do not depend on the order)
-          q_tile_new = ca->tile_order ? ca->tile_order[base] : base;
+          // unit -> (tile slot, frame): a staged launch queues every frame of a tile as a unit of its own
+          uint32_t slot = base, q_frame_new = 0;
+          if (ca->staging) { slot = base / ca->n_frames; q_frame_new = base - slot * ca->n_frames; }
+          q_tile_new = ca->tile_order ? ca->tile_order[slot] : slot;
           const uint32_t tile = q_tile_new * ca->world + ca->rank;
           const uint32_t tx = tile % ca->tiles_x, ty = tile / ca->tiles_x;
           const uint32_t pu = tx * 8u + (lane & 7u), pv = ty * 8u + (lane >> 3);
@@ -399,10 +425,10 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
           if (wants && !got) {
             const uint32_t w = my - avail;
             rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
-            my_tile = q_tile_new;
+            my_tile = q_tile_new; k = q_frame_new;
             got = true;
           }
-          q_tile = q_tile_new;
+          q_tile = q_tile_new; q_frame = q_frame_new;
           q_cur = base * 64u + (n_need - avail);
           q_end = base * 64u + 64u;
         } else {
@@ -420,7 +446,9 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
           const uint32_t uvp = as_u32(rec0.w);
           pix = (size_t)(uvp >> 16) * ca->width + (uvp & 0xffffu);
           seed_xy = as_u32(rec1.w);
-          if (accum_f32) {
+          if (ca->staging) {
+            // the image is touched by rt_combine_frames_kernel only
+          } else if (accum_f32) {
             const f32x4 c = reinterpret_cast<const f32x4*>(ca->accum)[pix];
             acc0 = c.x; acc1 = c.y; acc2 = c.z; acc3 = c.w;
           } else {
@@ -428,8 +456,8 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
             acc0 = unorm8_to_f32(q & 255u); acc1 = unorm8_to_f32((q >> 8) & 255u);
             acc2 = unorm8_to_f32((q >> 16) & 255u); acc3 = unorm8_to_f32(q >> 24);
           }
-          k = 0;
-          rng = seed_xy ^ (ca->frame_table ? ca->frame_table[0].x : ca->seed_t0);
+          // k = first frame of this unit: 0, or the unit's frame in a staged launch (set at the hand-out above)
+          rng = seed_xy ^ (ca->frame_table ? ca->frame_table[k].x : ca->seed_t0);
           rng = rng_step(rng);  // initialize_rng's discarded rand() (wgsl:262)
           if (COUNT) c_rand++;
           sample = 0; sumx = sumy = sumz = 0.0f;
@@ -687,6 +715,38 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
   }
 }
 
+// Second half of a STAGED launch: one thread per covered pixel of this rank's tiles folds the n_frames staged
+// colours into the accumulation pixel with combine_frame, in frame order - the recurrence the path kernel
+// runs per pixel in a pixel-sequential launch, operation for operation.
+__global__ __launch_bounds__(256) void rt_combine_frames_kernel(const rt_kargs a) {
+  const uint32_t pu = blockIdx.x * 64u + (threadIdx.x & 63u), pv = blockIdx.y * 4u + (threadIdx.x >> 6);
+  if (pu >= a.cov_w || pv >= a.cov_h) return;
+  const uint32_t tile = (pv >> 3) * a.tiles_x + (pu >> 3);
+  if (tile % a.world != a.rank) return;
+  const bool accum_f32 = (a.flags & RT_ACCUM_F32) != 0, combine_sum = (a.flags & RT_COMBINE_SUM) != 0;
+  const size_t pix = (size_t)pv * a.width + pu, npix = (size_t)a.width * a.height;
+  float acc0, acc1, acc2, acc3;
+  if (accum_f32) {
+    const f32x4 c = reinterpret_cast<const f32x4*>(a.accum)[pix];
+    acc0 = c.x; acc1 = c.y; acc2 = c.z; acc3 = c.w;
+  } else {
+    const uint32_t q = reinterpret_cast<const uint32_t*>(a.accum)[pix];
+    acc0 = unorm8_to_f32(q & 255u); acc1 = unorm8_to_f32((q >> 8) & 255u);
+    acc2 = unorm8_to_f32((q >> 16) & 255u); acc3 = unorm8_to_f32(q >> 24);
+  }
+  uint32_t q8 = 0;
+  for (uint32_t k = 0; k < a.n_frames; ++k) {
+    const f32x4 p = a.staging[(size_t)k * npix + pix];
+    q8 = combine_frame(acc0, acc1, acc2, acc3, p.x, p.y, p.z, as_f32(a.frame_table[k].y), combine_sum, accum_f32);
+  }
+  if (accum_f32) {
+    f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
+    reinterpret_cast<f32x4*>(a.accum)[pix] = o;
+  } else {
+    reinterpret_cast<uint32_t*>(a.accum)[pix] = q8;
+  }
+}
+
 // Tile order for the next launch: counting sort of this launch's per-tile cost, dearest first.
 // One workgroup; order[] becomes a permutation of [0, n) whatever the costs are.
 __global__ __launch_bounds__(1024) void rt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n) {
@@ -742,6 +802,13 @@ hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool stric
     if (count) hipLaunchKernelGGL((rt_path_kernel<false, true, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rt_path_kernel<false, false, false>), grid, block, 0, stream, a);
   }
+  return hipGetLastError();
+}
+
+hipError_t rt_launch_combine_frames(const rt_kargs& a, hipStream_t stream) {
+  if (!a.staging || !a.frame_table || a.n_frames == 0 || a.cov_w == 0 || a.cov_h == 0) return hipErrorInvalidValue;
+  const dim3 grid((a.cov_w + 63u) / 64u, (a.cov_h + 3u) / 4u), block(256);
+  hipLaunchKernelGGL(rt_combine_frames_kernel, grid, block, 0, stream, a);
   return hipGetLastError();
 }
 

@@ -503,3 +503,25 @@ def test_fuzzed_scenes_stay_bit_exact(seed):
     cam = scenes.camera_raw(48, 32, spp=3, frames=2, **camkw)
     for counters in (False, True):
         _strict_equals_oracle(R, 48, 32, 3, 2, flags, spheres, mats, cam, counters)
+
+
+@pytest.mark.parametrize("flags", [0, O.ACCUM_F32, O.ACCUM_F32 | O.COMBINE_SUM, O.DISPATCH_FULL], ids=["rgba8", "f32", "f32_sum", "rgba8_full"])
+def test_staged_batches_equal_pixel_sequential_batches_and_the_oracle(flags, monkeypatch):
+    """A batch whose rank has few tiles per wave is rendered as (tile, frame) units into a staging buffer and
+    folded into the image by a second kernel; RT_STAGED_FRAMES=0 keeps it pixel-sequential. Both must give
+    the oracle's image and RNG states, also under a tile partition."""
+    R = _rt()
+    W, H, spp, frames = 104, 72, 4, 5
+    spheres, mats = scenes.default_scene(1)
+    cam = scenes.camera_raw(W, H, spp=spp, frames=frames)
+    for rank, world in ((0, 1), (1, 3)):
+        img = O.OracleImage(W, H, flags)
+        O.render(img, spheres, mats, cam, 0, frames, rank=rank, world=world)
+        for staged in ("1", "0"):
+            monkeypatch.setenv("RT_STAGED_FRAMES", staged)
+            rt = _run_gpu(R, W, H, flags, spheres, mats, cam, frames, batched=True, rank=rank, world=world)
+            assert np.array_equal(rt.read_rng_state(), img.rng), (staged, rank, world)
+            if flags & O.ACCUM_F32:
+                assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32)), (staged, rank, world)
+            assert np.array_equal(rt.read_rgba8(), img.view_rgba8()), (staged, rank, world)
+            rt.close()
