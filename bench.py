@@ -21,6 +21,7 @@ resident in HBM, RT_MATH_STRICT (the mode that is bit-identical to the oracle). 
   cpu_baseline the oracle (scalar C port, OpenMP) timed on this box's host cores on a bounded
                tile sample of the same frame (rank 0, N = 1 only).
   fast_math    the same measurement in RT_MATH_FAST (image within tolerance, not bit-exact).
+  batched_render the same frames as one rt_render_frames launch (N = 1 only; staged (tile, frame) units).
 """
 import argparse
 import json
@@ -120,6 +121,31 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
     samples_per_step = cov_w * cov_h * spp * (world if split == "frames" else 1)
     return {"seconds": seconds, "kernel_ms": kernel_ms, "launches": launches, "counters": counters,
             "flops_per_launch": algorithmic_flops(counters), "samples_per_step": samples_per_step, "device": info}
+
+
+def measure_batched(R, cfg, flags, frames, device):
+    """The same frames submitted as ONE rt_render_frames batch (what App::run does): (tile, frame) work units,
+    so the launch does not end on one pixel's whole sample loop. Same arithmetic, bit-identical images."""
+    from raytracer_amd import host
+
+    W, H, spp = cfg["width"], cfg["height"], cfg["spp"]
+    rt = R.Raytracer(W, H, flags, device=device)
+    rt.set_scene(cfg["spheres"], cfg["materials"])
+    tb = host.time_table(2 * frames)
+    cam = host.camera_raw(W, H, spp=spp, frames=2 * frames)
+    rt.set_camera(cam)
+    rt.render_frames(tb[:frames])  # warm-up batch (also measures the tile order)
+    rt.sync()
+    t0 = time.perf_counter()
+    rt.render_frames(tb[frames:])
+    rt.sync()
+    seconds = time.perf_counter() - t0
+    rt.close()
+    cov_w = W if flags & R.RT_DISPATCH_FULL else (W // 16) * 16
+    cov_h = H if flags & R.RT_DISPATCH_FULL else (H // 16) * 16
+    return {"value": cov_w * cov_h * spp * frames / seconds, "unit": "samples/s", "frames_per_launch": frames,
+            "ms_per_frame": seconds * 1e3 / frames,
+            "note": "one rt_render_frames launch; bit-identical to the per-frame passes that `value` times"}
 
 
 def cpu_baseline(cfg, flags, target_seconds):
@@ -266,6 +292,9 @@ def main():
                                     "ms_per_step": extras["seconds"] * 1e3 / args.steps, "roofline": roof(extras, other),
                                     "parity": "image within PSNR >= 40 dB of strict; RNG function bit-exact" if other == "fast"
                                     else "bit-identical to the oracle"}
+        if world == 1 and not args.no_extras:
+            out["batched_render"] = measure_batched(R, cfg, base_flags | (R.RT_MATH_FAST if args.math == "fast" else 0),
+                                                    max(args.steps, 2), local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, base_flags, args.cpu_seconds)
         print(json.dumps(out), flush=True)
