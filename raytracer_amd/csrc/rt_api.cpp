@@ -169,11 +169,18 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
       (void)hipFree(ctx->staging);
       ctx->staging = nullptr;
       ctx->staging_bytes = 0;
-      RT_HIP(hipMalloc((void**)&ctx->staging, stage_bytes));
-      ctx->staging_bytes = stage_bytes;
+      if (hipMalloc((void**)&ctx->staging, stage_bytes) == hipSuccess) {
+        ctx->staging_bytes = stage_bytes;
+      } else {
+        (void)hipGetLastError();   // no room for the staging buffer: this context keeps its batches pixel-sequential
+        ctx->staging = nullptr;
+        ctx->use_staging = 0;
+      }
     }
-    a.staging = ctx->staging;
-    a.n_units = my_tiles * n_frames;
+    if (ctx->staging) {
+      a.staging = ctx->staging;
+      a.n_units = my_tiles * n_frames;
+    }
   }
   const uint32_t n_waves = (uint32_t)(resident < a.n_units ? resident : a.n_units);
   // host-side shape check before the launch: every tile index a block can form is < n_tiles or
