@@ -131,3 +131,49 @@ def test_c3_checker_4k_tile_band_bit_exact():
     assert np.array_equal(rt.read_rng_state(), img.rng)
     assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
     rt.close()
+
+
+FULL_SIZE = {
+    # checksums.json key: (W, H, spp, frames, flags, scene) -- the BASELINE configs at full size
+    "C2_1920x1080_16spp_256frames": (1920, 1080, 16, 256, 0, ("default", 1)),
+    "C3_3840x2160_64spp_8frames": (3840, 2160, 64, 8, O.ACCUM_F32 | O.SHADE_CHECKER, ("bunch", 20, 3, 3)),
+    "C4_1920x1080_4spp_16frames": (1920, 1080, 4, 16, 0, ("bunch", 1024, 16, 4)),
+    "C5_7680x4320_1spp_first16frames": (7680, 4320, 1, 16, O.ACCUM_F32 | O.COMBINE_SUM, ("default", 1)),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL_SIZE))
+@pytest.mark.parametrize("mode", ["batched", "per_frame"])
+def test_full_size_configs_match_the_oracles_checksums(name, mode):
+    """Every pixel of the complete BASELINE renders: SHA-256 of the RGBA8 image, of every pixel's final RNG state
+    and of the float image, against the digests the CPU oracle produced (tests/golden/make_golden.py --full;
+    minutes of CPU per config, so the digests are committed instead of being recomputed here)."""
+    import raytracer_amd as R
+    from raytracer_amd import host
+
+    sums = G.checksums()
+    if name not in sums:
+        pytest.skip("digest not generated (make_golden.py --full)")
+    W, H, spp, frames, flags, spec = FULL_SIZE[name]
+    if mode == "per_frame" and frames > 16:
+        pytest.skip("per-frame launches are covered by the shorter configs")
+    spheres, mats = host.scene_default(spec[1]) if spec[0] == "default" else host.scene_random_bunch(spec[1], spec[2], spec[3])
+    rt = R.Raytracer(W, H, flags | R.RT_MATH_STRICT)
+    rt.set_scene(spheres, mats)
+    rt.enable_rng_capture(True)
+    cam = host.camera_raw(W, H, spp=spp, frames=frames)
+    tb = host.time_table(frames)
+    if mode == "batched":
+        rt.set_camera(cam)
+        for s in range(0, frames, 64):
+            rt.render_frames(tb[s:s + 64])
+    else:
+        for f in range(frames):
+            rt.set_time(int(tb[f])); rt.set_camera(cam); rt.compute()
+            cam["current_frame"] += 1
+    want = sums[name]
+    assert hashlib.sha256(rt.read_rng_state().tobytes()).hexdigest() == want["rng_sha256"]
+    assert hashlib.sha256(np.ascontiguousarray(rt.read_rgba8()).tobytes()).hexdigest() == want["rgba8_sha256"]
+    if flags & O.ACCUM_F32:
+        assert hashlib.sha256(rt.read_accum_f32().tobytes()).hexdigest() == want["accum_sha256"]
+    rt.close()
