@@ -36,7 +36,6 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) f32x4* const_f32x4_ptr;  // scalar-load path
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
