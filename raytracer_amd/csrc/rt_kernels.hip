@@ -52,8 +52,9 @@ __device__ __forceinline__ uint32_t rng_step(uint32_t rng) {
 // 23 mantissa bits k of the state, rand() = m exactly, and both -0.5 + m = (k - 2^22) 2^-23 and
 // 2 m - 1 = (2k - 2^23) 2^-23 are representable, so every correctly rounded way of computing them gives
 // the same bits: (1 + m) - 1.5 and (2 + 2m) - 3, the left operands being bit patterns.
-__device__ __forceinline__ float rng_jitter(uint32_t rng) { return as_f32((rng & 0x007fffffu) | 0x3f800000u) - 1.5f; }
-__device__ __forceinline__ float rng_signed(uint32_t rng) { return as_f32((rng & 0x007fffffu) | 0x40000000u) - 3.0f; }
+// ((rng & mask) | exponent) as v_bitop3_b32 (table 0xEA = (a & b) | c): 2.8 issue cycles against 4.3 for v_and_or_b32
+__device__ __forceinline__ float rng_jitter(uint32_t rng) { return as_f32(__builtin_amdgcn_bitop3_b32(rng, 0x007fffffu, 0x3f800000u, 0xEA)) - 1.5f; }
+__device__ __forceinline__ float rng_signed(uint32_t rng) { return as_f32(__builtin_amdgcn_bitop3_b32(rng, 0x007fffffu, 0x40000000u, 0xEA)) - 3.0f; }
 #define RT_STEP(dst)        \
   do {                      \
     rng = rng_step(rng);    \
@@ -131,6 +132,16 @@ __device__ __forceinline__ float div_rn(float x, const rn_divisor& d) {
   }
   return q;
 }
+// x / y for a caller that knows more than the operand ranges: `generic` marks the lanes whose operands may
+// leave the range div_core is correctly rounded for (they take the compiler's division), `any_generic` is the
+// wave-uniform "some lane does" - both computed once per ray instead of two compares per quotient.
+__device__ __forceinline__ float div_known(float x, const rn_divisor& d, bool generic, bool any_generic) {
+  float q = div_core(x, d);
+  if (__builtin_expect(any_generic, 0)) {
+    if (generic) q = x / d.y;
+  }
+  return q;
+}
 // x0 / y, x1 / y and x2 / y
 __device__ __forceinline__ void div3_rn(float x0, float x1, float x2, const rn_divisor& d, float& q0, float& q1, float& q2) {
   q0 = div_core(x0, d); q1 = div_core(x1, d); q2 = div_core(x2, d);
@@ -183,9 +194,10 @@ __device__ __forceinline__ uint32_t phase1_pair(uint32_t missbits, f32x2 cx, f32
   const f32x2 test = __builtin_elementwise_fma(nhb, nhb, w);
   // BEHIND CULL: w < 0 means the origin is outside the sphere by more than the margin; if then
   // hb > 0 both roots are negative (the sphere lies behind the ray) and hit_sphere rejects them.
-  // Proof that the literal arithmetic agrees in DESIGN.md. One v_and_or: sign = (nhb & w) | test.
-  const uint32_t key0 = CULL ? ((as_u32(nhb.x) & as_u32(w.x)) | as_u32(test.x)) : as_u32(test.x);
-  const uint32_t key1 = CULL ? ((as_u32(nhb.y) & as_u32(w.y)) | as_u32(test.y)) : as_u32(test.y);
+  // Proof that the literal arithmetic agrees in DESIGN.md. One v_bitop3: sign = (nhb & w) | test.
+  // v_bitop3_b32 (truth table 0xEA = (a & b) | c) issues in 2.8 cycles against 4.3 for v_and_or_b32 (profiles/r1e_valu_ubench.txt)
+  const uint32_t key0 = CULL ? __builtin_amdgcn_bitop3_b32(as_u32(nhb.x), as_u32(w.x), as_u32(test.x), 0xEA) : as_u32(test.x);
+  const uint32_t key1 = CULL ? __builtin_amdgcn_bitop3_b32(as_u32(nhb.y), as_u32(w.y), as_u32(test.y), 0xEA) : as_u32(test.y);
   missbits = __builtin_amdgcn_alignbit(missbits, key0, 31);  // (missbits << 1) | sign
   return __builtin_amdgcn_alignbit(missbits, key1, 31);
 }
@@ -317,13 +329,11 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
     // 1/64 occupancy in every other iteration. Lanes park in FRAME_END / NEED_PIXEL until `batch_lanes`
     // of them wait, or nothing else is runnable in the wave.
     const unsigned long long parked = __ballot(state - ST_NEED_PIXEL < 2u);  // NEED_PIXEL or FRAME_END
-    bool service = false;  // wave-uniform; most iterations have no parked lane and skip all of this
-    rt_kargs_cptr ca = (rt_kargs_cptr)0;
-    if (parked) {
-      ca = cold_args();
-      service = (uint32_t)__popcll(parked) >= ca->batch_lanes || !__ballot(state >= ST_READY);
-    }
-    if (service && state == ST_FRAME_END) {
+    // wave-uniform; most iterations have no parked lane and skip all of this with one scalar branch
+    if (__builtin_expect(parked != 0ull, 0)) {
+    const rt_kargs_cptr ca = cold_args();
+    if ((uint32_t)__popcll(parked) >= ca->batch_lanes || !__ballot(state >= ST_READY)) {
+    if (state == ST_FRAME_END) {
       // ---- end of this pixel's frame: color / spp (wgsl:122), store_color (wgsl:96-112) ----
       float p0, p1, p2;
       if (ca->inv_spp > 0.0f) {  // spp is a power of two: x / spp == x * (1/spp) exactly
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
     }
 
     // ================= [A] hand out pixels =================
-    const unsigned long long need = service ? __ballot(state == ST_NEED_PIXEL) : 0ull;
+    const unsigned long long need = __ballot(state == ST_NEED_PIXEL);
     if (need) {
       const uint32_t n_need = (uint32_t)__popcll(need);
       const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
@@ -465,7 +475,9 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         }
       }
     }
-    if (service && !__ballot(state != ST_DEAD)) break;  // every lane drained and the queue is empty (lanes die in [A] only)
+    if (!__ballot(state != ST_DEAD)) break;  // every lane drained and the queue is empty (lanes die in [A] only)
+    }  // service
+    }  // parked
 
     // ================= [G] random draws =================
     // Round 0 is shared: lanes starting a sample draw the two jitter numbers of get_random_ray
@@ -511,9 +523,13 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
     if (state == ST_GOT_DIR) {
       // rec.normal + normalize(p) (wgsl:165,292-294), once per accepted lane after all rounds
       if (STRICT) {
+        // the components of an accepted point are 0 or multiples of 2^-22 in (-1, 1) and |p| >= 2^-22 unless p = 0:
+        // all inside div_core's range (a +0 component gives +0 like the IEEE quotient); p = 0 (0/0) goes the generic way
         const rn_divisor len = make_divisor(sqrt_rn(gl2));
-        float ux, uy, uz;
-        div3_rn(gqx, gqy, gqz, len, ux, uy, uz);
+        const bool zero_len = !(gl2 >= 0x1p-50f);
+        const bool any_zero_len = __ballot(zero_len) != 0ull;
+        const float ux = div_known(gqx, len, zero_len, any_zero_len), uy = div_known(gqy, len, zero_len, any_zero_len),
+                    uz = div_known(gqz, len, zero_len, any_zero_len);
         dx = dx + ux; dy = dy + uy; dz = dz + uz;
       } else {
         const float il = __builtin_amdgcn_rsqf(gl2);
@@ -556,6 +572,12 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
       } else {
         inv_a = __builtin_amdgcn_rcpf(a_fast);
       }
+      // STRICT roots (-hb -+ sq) / a_lit of a tame ray: |hb|, sq < 2^32 and a_lit in [2^-21, 2^21], so the numerator
+      // is below div_core's upper limit, and a numerator under its lower limit 2^-60 gives |quotient| < 2^-38 both
+      // exactly and from div_core - far below RT_RAY_TMIN, where only the comparison `root <= tmin` is used.
+      // Untamed rays take the compiler's division.
+      const bool any_untame = __ballot(!tame) != 0ull;
+      const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
       if (COUNT) { c_R++; c_T += n_spheres; }
       RT_PROF_END(1);
       for (uint32_t base = 0; base < n_spheres; base += 32u) {
@@ -572,7 +594,8 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         RT_PROF_BEGIN(3);
         // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
         // (untamed rays take every sphere; the lowest cnt_pad - cnt bits are padding spheres)
-        uint32_t cand = tame ? ~missbits : ((cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u));
+        const uint32_t valid = (cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u);  // wave-uniform
+        uint32_t cand = (~missbits | untame_fill) & valid;
         while (cand) {
 #if RT_PROFILE_SECTIONS
           prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true));
@@ -591,10 +614,10 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
             if (!(disc < 0.0f)) {
               if (COUNT) c_D++;
               const float sq = sqrt_rn(disc);
-              float root = div_rn(-hb - sq, a_div);
+              float root = div_known(-hb - sq, a_div, !tame, any_untame);
               bool ok = true;
               if (root <= RT_RAY_TMIN || closest <= root) {
-                root = div_rn(-hb + sq, a_div);
+                root = div_known(-hb + sq, a_div, !tame, any_untame);
                 if (root <= RT_RAY_TMIN || closest <= root) ok = false;
               }
               if (ok) { closest = root; hit = (int)i; }

@@ -98,6 +98,49 @@ __global__ __launch_bounds__(64) void k(float* out, float s0, int n, unsigned lo
 #define OP(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(p[i]) : "s"(sc), "v"(p[(i + 1) & 7])); asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(p[i]) : "s"(sc), "v"(p[(i + 2) & 7]));
       BODY8(OP)
 #undef OP
+    } else if (KIND == 18) {  // v_mad_u64_u32: rng * A + C in one instruction (VGPR multiplier, SGPR-pair addend)
+      unsigned long long cadd = 182489729ull + (unsigned long long)(c0 > 1e30f);
+      unsigned long long d64;
+      unsigned mulv = 18197u + (threadIdx.x >> 8);
+#define OP(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=&v"(d64) : "v"(u[i]), "v"(mulv), "s"(cadd) : "vcc"); u[i] = (unsigned)d64;
+      BODY8(OP) BODY8(OP)
+#undef OP
+    } else if (KIND == 19) {  // v_and_or_b32
+#define OP(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7])); asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 3) & 7]), "v"(u[(i + 4) & 7]));
+      BODY8(OP)
+#undef OP
+    } else if (KIND == 20) {  // v_xor_b32 alone
+#define OP(i) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 3) & 7]));
+      BODY8(OP)
+#undef OP
+    } else if (KIND == 21) {  // v_add_u32 alone
+#define OP(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7])); asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 3) & 7]));
+      BODY8(OP)
+#undef OP
+    } else if (KIND == 22) {  // v_rsq_f32
+#define OP(i) asm volatile("v_rsq_f32 %0, %0" : "+v"(r[i])); asm volatile("v_rsq_f32 %0, %0" : "+v"(q[i]));
+      BODY8(OP)
+#undef OP
+    } else if (KIND == 23) {  // v_mov_b32
+#define OP(i) asm volatile("v_mov_b32 %0, %1" : "=v"(r[i]) : "v"(q[(i + 1) & 7])); asm volatile("v_mov_b32 %0, %1" : "=v"(q[i]) : "v"(r[(i + 3) & 7]));
+      BODY8(OP)
+#undef OP
+    } else if (KIND == 24) {  // v_bitop3_b32
+#define OP(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x3a" : "+v"(u[i]) : "v"(u[(i + 1) & 7]), "v"(u[(i + 2) & 7])); asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x3a" : "+v"(u[i]) : "v"(u[(i + 3) & 7]), "v"(u[(i + 4) & 7]));
+      BODY8(OP)
+#undef OP
+    } else if (KIND == 25) {  // v_med3_f32
+#define OP(i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(q[i]), "v"(c1)); asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(c1), "v"(c0));
+      BODY8(OP)
+#undef OP
+    } else if (KIND == 26) {  // v_cmp_lt_f32 -> vcc, v_addc_co_u32 (shift a sign into a mask through the carry)
+#define OP(i) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(u[i]) : "v"(q[i]), "v"(c0) : "vcc");
+      BODY8(OP)
+#undef OP
+    } else if (KIND == 27) {  // s_nop 1 between VALU (hazard filler as the compiler emits it)
+#define OP(i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_nop 1" : "+v"(r[i]) : "v"(q[i]), "v"(c1)); asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(q[i]) : "v"(c1), "v"(c0));
+      BODY8(OP)
+#undef OP
     } else if (KIND == 16) {  // v_fma + exec-mask juggling as a divergent `if` compiles to (v_cmp, s_and_saveexec, s_or)
 #define OP(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[i]) : "v"(q[i]), "v"(c1)); asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\ts_and_saveexec_b64 s[20:21], vcc\n\tv_fma_f32 %0, %0, %2, %1\n\ts_or_b64 exec, exec, s[20:21]" : "+v"(q[i]) : "v"(c1), "v"(c0) : "vcc", "s20", "s21");
       BODY8(OP)
@@ -138,9 +181,9 @@ int main() {
   float* d; CHECK(hipMalloc(&d, 4));
   unsigned long long* st; CHECK(hipMalloc(&st, 16));
   const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_subrev_f32(sgpr)", "v_alignbit_b32", "v_mul_lo_u32", "v_sqrt_f32", "v_rcp_f32",
-                         "v_lshlrev+v_xor", "v_cmp+v_cndmask", "v_mad_u32_u24", "v_mul_f32", "v_fma_f32(sgpr)", "v_pk_mul/add_f32", "v_fma_f32 dep-chain", "fma+salu 1:1 (per fma)", "fma+salu 2:1 (per fma)", "fma,[cmp,saveexec,fma,or]", "v_pk_fma_f32(sgpr pair,bcast)"};
+                         "v_lshlrev+v_xor", "v_cmp+v_cndmask", "v_mad_u32_u24", "v_mul_f32", "v_fma_f32(sgpr)", "v_pk_mul/add_f32", "v_fma_f32 dep-chain", "fma+salu 1:1 (per fma)", "fma+salu 2:1 (per fma)", "fma,[cmp,saveexec,fma,or]", "v_pk_fma_f32(sgpr pair,bcast)", "v_mad_u64_u32", "v_and_or_b32", "v_xor_b32", "v_add_u32", "v_rsq_f32", "v_mov_b32", "v_bitop3_b32", "v_med3_f32", "v_cmp+v_addc (pair)", "fma+s_nop 1 (per fma)"};
   printf("%-22s %8s %8s %8s %8s   (cycles @2.4GHz per wave64 instruction per SIMD)\n", "instruction", "1w/SIMD", "2w", "4w", "8w");
 #define ROW(K) { printf("%-22s", names[K]); for (int w : {1, 2, 4, 8}) { double g, c; double x = run<K>(w, d, cus, st, &g, &c); printf(" %6.2f (%4.2f real @%4.2fGHz)", x, c, g); } printf("\n"); }
-  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12) ROW(13) ROW(14) ROW(15) ROW(17)
+  ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12) ROW(13) ROW(14) ROW(15) ROW(17) ROW(18) ROW(19) ROW(20) ROW(21) ROW(22) ROW(23) ROW(24) ROW(25) ROW(26) ROW(27)
   return 0;
 }
