@@ -97,6 +97,11 @@ int rt_reset_counters(rt_ctx* ctx);
  * plain sum (RCCL reduce). Default rank 0 of 1. */
 int rt_set_partition(rt_ctx* ctx, uint32_t rank, uint32_t world);
 
+/* Sky tiles (no counterpart in the reference; diagnostic): how many of this context's 8x8 tiles the last pass
+ * finished without tracing because no primary ray of theirs can hit a sphere ("sky tiles"), out of
+ * `tiles` tiles of its partition. Both 0 before the first pass or with RT_SKY_TILES=0 in the environment. */
+int rt_sky_tile_stats(rt_ctx* ctx, uint32_t* sky_tiles, uint32_t* tiles);
+
 /* Plumbing for callers that own device memory / streams (torch.distributed, HIP graphs):
  * rt_accum_device_ptr: device address and byte size of the accumulation image (RGBA8: W*H*4,
  *   F32: W*H*16), valid until rt_destroy.

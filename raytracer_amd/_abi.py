@@ -62,6 +62,7 @@ SIGNATURES = {
     "rt_get_counters": (C.c_int, [_VP, C.POINTER(RtCounters)]),
     "rt_reset_counters": (C.c_int, [_VP]),
     "rt_set_partition": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
+    "rt_sky_tile_stats": (C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rt_accum_device_ptr": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_size_t)]),
     "rt_bind_accum": (C.c_int, [_VP, _VP, C.c_size_t]),
     "rt_set_stream": (C.c_int, [_VP, _VP]),

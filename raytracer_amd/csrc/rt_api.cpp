@@ -51,6 +51,12 @@ struct rt_ctx {
   bool have_order = false;
   uint32_t order_age = 0;     // launches since the cost was last measured
   int use_order = 1;          // env RT_TILE_ORDER=0 disables the feedback
+  // sky tiles: per-tile "no primary ray can hit a sphere" flags for the current scene, camera and partition
+  uint32_t* sky_flags = nullptr;
+  uint32_t sky_tiles_cap = 0;  // my_tiles the buffer is sized for
+  uint32_t sky_key = 0;        // rank/world the flags were computed under
+  bool sky_valid = false;
+  int use_sky = 1;             // env RT_SKY_TILES=0 traces every tile
   int compute_units = 0;
   int waves_per_cu = 0;       // launch width override (0 = default); env RT_WAVES_PER_CU
   int reject_tries = 0;       // rejection rounds override (0 = default); env RT_REJECT_TRIES
@@ -225,6 +231,26 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     }
     a.tile_order = ctx->have_order ? ctx->tile_order : nullptr;
   }
+  // Sky tiles: recomputed (inside the timed region) whenever the scene, the camera or the partition changed.
+  // Counting launches trace every tile, so their event counters stay the oracle's.
+  if (ctx->use_sky && !ctx->counting) {
+    if (ctx->sky_tiles_cap != my_tiles) {
+      RT_HIP(hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->sky_flags);
+      ctx->sky_flags = nullptr;
+      ctx->sky_tiles_cap = 0;
+      RT_HIP(hipMalloc((void**)&ctx->sky_flags, my_tiles * sizeof(uint32_t)));
+      ctx->sky_tiles_cap = my_tiles;
+      ctx->sky_valid = false;
+    }
+    if (ctx->sky_key != key) ctx->sky_valid = false;
+    ctx->sky_key = key;
+    if (!ctx->sky_valid) {
+      RT_HIP(rt_launch_sky_tiles(a, ctx->sky_flags, ctx->stream));
+      ctx->sky_valid = true;
+    }
+    a.sky_flags = ctx->sky_flags;
+  }
   RT_HIP(hipMemsetAsync(ctx->queue, 0, sizeof(uint32_t), ctx->stream));
   RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, ctx->stream));
   if (a.staging) RT_HIP(rt_launch_combine_frames(a, ctx->stream));
@@ -280,6 +306,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e3 = std::getenv("RT_BATCH_LANES")) c->batch_lanes = std::atoi(e3);
   if (const char* e4 = std::getenv("RT_TILE_ORDER")) c->use_order = std::atoi(e4);
   if (const char* e5 = std::getenv("RT_STAGED_FRAMES")) c->use_staging = std::atoi(e5);
+  if (const char* e6 = std::getenv("RT_SKY_TILES")) c->use_sky = std::atoi(e6);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
   if (e == hipSuccess) {
     c->stream = c->own_stream;
@@ -311,6 +338,7 @@ void rt_destroy(rt_ctx* c) {
   (void)hipFree(c->queue);
   (void)hipFree(c->tile_cost);
   (void)hipFree(c->tile_order);
+  (void)hipFree(c->sky_flags);
   (void)hipFree(c->sph_p1);
   (void)hipFree(c->sph_test);
   (void)hipFree(c->sph_shade);
@@ -380,6 +408,7 @@ int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, cons
   ctx->n_spheres = n_spheres;
   ctx->p1_tame = tame;
   ctx->have_order = false;  // per-tile cost belongs to the old scene
+  ctx->sky_valid = false;
   ctx->have_scene = true;
   return RT_OK;
 }
@@ -391,8 +420,10 @@ int rt_set_camera(rt_ctx* ctx, const rt_camera_raw* camera) {
     return fail(RT_ERR_INVALID, "samples_per_pixel must be >= 1 (the reference clamps it to [1,256], camera.rs:136-137)");
   // a moved camera changes which tiles are dear: measure the per-tile cost again
   if (!ctx->have_camera || std::memcmp(ctx->camera.pixel_to_world, camera->pixel_to_world, sizeof camera->pixel_to_world) != 0 ||
-      std::memcmp(ctx->camera.pos, camera->pos, sizeof camera->pos) != 0)
+      std::memcmp(ctx->camera.pos, camera->pos, sizeof camera->pos) != 0) {
     ctx->have_order = false;
+    ctx->sky_valid = false;
+  }
   ctx->camera = *camera;
   ctx->have_camera = true;
   return RT_OK;
@@ -545,6 +576,21 @@ int rt_set_partition(rt_ctx* ctx, uint32_t rank, uint32_t world) {
   if (world == 0 || rank >= world) return fail(RT_ERR_INVALID, "need rank < world");
   ctx->rank = rank;
   ctx->world = world;
+  return RT_OK;
+}
+
+int rt_sky_tile_stats(rt_ctx* ctx, uint32_t* sky_tiles, uint32_t* tiles) {
+  if (int rc = check(ctx)) return rc;
+  if (!sky_tiles || !tiles) return fail(RT_ERR_INVALID, "null out pointer");
+  *sky_tiles = *tiles = 0;
+  RT_HIP(hipStreamSynchronize(ctx->stream));
+  if (!ctx->sky_flags || !ctx->sky_valid || ctx->sky_tiles_cap == 0) return RT_OK;  // no pass has used sky tiles yet
+  std::vector<uint32_t> h(ctx->sky_tiles_cap);
+  RT_HIP(hipMemcpy(h.data(), ctx->sky_flags, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  uint32_t n = 0;
+  for (uint32_t f : h) n += f != 0u;
+  *sky_tiles = n;
+  *tiles = ctx->sky_tiles_cap;
   return RT_OK;
 }
 

@@ -123,15 +123,6 @@ __device__ __forceinline__ float div_core(float x, const rn_divisor& d) {
   q = __builtin_fmaf(__builtin_fmaf(-d.y, q, x), d.r, q);
   return q;
 }
-__device__ __forceinline__ float div_rn(float x, const rn_divisor& d) {
-  float q = div_core(x, d);
-  const float ax = __builtin_fabsf(x);
-  const bool rare = !(d.nice && ax >= 0x1p-60f && ax <= 0x1p60f);  // NaN operands are rare too
-  if (RT_RARELY(rare)) {
-    if (rare) q = x / d.y;
-  }
-  return q;
-}
 // x / y for a caller that knows more than the operand ranges: `generic` marks the lanes whose operands may
 // leave the range div_core is correctly rounded for (they take the compiler's division), `any_generic` is the
 // wave-uniform "some lane does" - both computed once per ray instead of two compares per quotient.
@@ -388,6 +379,95 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
       const bool wants = state == ST_NEED_PIXEL;
       bool got = false;
       f32x4 rec0 = {0, 0, 0, 0}, rec1 = {0, 0, 0, 0};
+      uint32_t base = 0xffffffffu, q_frame_new = 0;
+      if (n_need > avail) {
+        // Fetch units until one has pixels to hand out. unit -> (tile slot, frame): a staged launch queues every frame
+        // of a tile as a unit of its own. Tiles come in the order of the previous launch's measured cost, dearest
+        // first, so the launch ends on cheap pixels (results do not depend on the order).
+        for (;;) {
+          base = 0xffffffffu;
+          if (more) {
+            if (lane == 0) base = atomicAdd(ca->queue, 1u);  // all 64 lanes are active here (uniform loop)
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= ca->n_units) { more = false; base = 0xffffffffu; }
+          }
+          if (base == 0xffffffffu) break;
+          uint32_t slot = base;
+          q_frame_new = 0;
+          if (ca->staging) { slot = base / ca->n_frames; q_frame_new = base - slot * ca->n_frames; }
+          q_tile_new = ca->tile_order ? ca->tile_order[slot] : slot;
+          if (COUNT || !ca->sky_flags || __builtin_amdgcn_readfirstlane(ca->sky_flags[q_tile_new]) == 0u) break;
+          // ---- SKY TILE, finished right here by all 64 lanes (lane = pixel, no divergence; the lanes' own paths
+          // wait): rt_sky_tiles_kernel proved that every primary ray of this tile misses every sphere in the literal
+          // arithmetic ("sky tiles"). Each sample is then get_random_ray's two draws and the miss
+          // colour (wgsl:174-180, 144-148, 131-134) - no trace.
+          const uint32_t tile = q_tile_new * ca->world + ca->rank;
+          const uint32_t tx = tile % ca->tiles_x, ty = tile / ca->tiles_x;
+          const uint32_t pu = tx * 8u + (lane & 7u), pv = ty * 8u + (lane >> 3);
+          if (pu < ca->cov_w && pv < ca->cov_h) {
+            const float vx = (float)pu, vy = (float)(ca->height - pv);
+            const float wx = (float)(pu + 1u), wy = (float)(ca->height - (pv + 1u));
+            const __attribute__((address_space(4))) float* m = ca->p2w;  // column-major
+            const float spcy = ((m[1] * vx + m[5] * vy) + m[9] * 0.0f) + m[13] * 1.0f;           // pixel_center.y
+            const float spdy = (((m[1] * wx + m[5] * wy) + m[9] * 0.0f) + m[13] * 1.0f) - spcy;  // pixel_delta.y
+            const size_t spix = (size_t)pv * ca->width + pu;
+            const uint32_t sseed = rng_seed_pixel(pu, pv);
+            float b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+            if (ca->staging) {
+              // the image is touched by rt_combine_frames_kernel only
+            } else if (accum_f32) {
+              const f32x4 c = reinterpret_cast<const f32x4*>(ca->accum)[spix];
+              b0 = c.x; b1 = c.y; b2 = c.z; b3 = c.w;
+            } else {
+              const uint32_t q = reinterpret_cast<const uint32_t*>(ca->accum)[spix];
+              b0 = unorm8_to_f32(q & 255u); b1 = unorm8_to_f32((q >> 8) & 255u);
+              b2 = unorm8_to_f32((q >> 16) & 255u); b3 = unorm8_to_f32(q >> 24);
+            }
+            const uint32_t kf0 = ca->staging ? q_frame_new : 0u, kf1 = ca->staging ? q_frame_new + 1u : ca->n_frames;
+            uint32_t srng = 0, q8 = 0;
+            for (uint32_t kf = kf0; kf < kf1; ++kf) {
+              srng = rng_step(sseed ^ (ca->frame_table ? ca->frame_table[kf].x : ca->seed_t0));  // initialize_rng (wgsl:254-263)
+              float ssx = 0.0f, ssy = 0.0f, ssz = 0.0f;
+              for (uint32_t sm = 0; sm < ca->spp; ++sm) {
+                srng = rng_step(srng);  // px: does not reach the miss colour
+                srng = rng_step(srng);
+                const float sdy = spcy + rng_jitter(srng) * spdy;
+                float mx = 0.0f, my = 0.0f, mz = 0.0f;  // ray_color: color = 0, reflectance = 1
+                if (!checker) {
+                  const float t = 0.5f * (1.0f - sdy);
+                  const float it = 1.0f - t;
+                  mx = mx + (it + t * 0.5f) * 1.0f; my = my + (it + t * 0.7f) * 1.0f; mz = mz + (it + t * 1.0f) * 1.0f;
+                } else {
+                  mx = mx + 0.0f * 1.0f; my = my + 0.0f * 1.0f; mz = mz + 0.0f * 1.0f;
+                }
+                ssx = ssx + mx; ssy = ssy + my; ssz = ssz + mz;  // send_rays (wgsl:120)
+              }
+              float p0, p1, p2;
+              if (ca->inv_spp > 0.0f) {
+                p0 = ssx * ca->inv_spp; p1 = ssy * ca->inv_spp; p2 = ssz * ca->inv_spp;
+              } else {
+                p0 = ssx / spp_f; p1 = ssy / spp_f; p2 = ssz / spp_f;
+              }
+              if (ca->staging) {
+                f32x4 o; o.x = p0; o.y = p1; o.z = p2; o.w = 1.0f;
+                ca->staging[(size_t)kf * ((size_t)ca->width * ca->height) + spix] = o;
+              } else {
+                const float cw = ca->frame_table ? as_f32(ca->frame_table[kf].y) : ca->cw0;
+                q8 = combine_frame(b0, b1, b2, b3, p0, p1, p2, cw, combine_sum, accum_f32);
+              }
+            }
+            if (!ca->staging) {
+              if (accum_f32) {
+                f32x4 o; o.x = b0; o.y = b1; o.z = b2; o.w = b3;
+                reinterpret_cast<f32x4*>(ca->accum)[spix] = o;
+              } else {
+                reinterpret_cast<uint32_t*>(ca->accum)[spix] = q8;
+              }
+            }
+            if (ca->rng_out && kf1 == ca->n_frames) ca->rng_out[spix] = srng;
+          }
+        }
+      }
       if (wants && my < avail) {  // a pixel of the tile already staged in LDS
         const uint32_t w = (q_cur + my) & 63u;
         rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
@@ -395,22 +475,10 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         got = true;
       }
       if (n_need > avail) {
-        uint32_t base = 0xffffffffu;
-        if (more) {
-          if (lane == 0) base = atomicAdd(ca->queue, 1u);  // all 64 lanes are active here (uniform loop)
-          base = __builtin_amdgcn_readfirstlane(base);
-          if (base >= ca->n_units) { more = false; base = 0xffffffffu; }
-        }
         if (base != 0xffffffffu) {
           // ---- stage tile `base`: all 64 lanes compute the per-pixel constants of its 64 pixels at full
           // occupancy (pixel_to_world, get_pixel_delta wgsl:85-94; the pixel part of the RNG seed
           // wgsl:258-259) into LDS; lanes pick their record up when they are handed the pixel.
-          // tiles are handed out in the order of the previous launch's measured cost, dearest first, so
-          // the launch ends on cheap pixels (results do not depend on the order)
-          // unit -> (tile slot, frame): a staged launch queues every frame of a tile as a unit of its own
-          uint32_t slot = base, q_frame_new = 0;
-          if (ca->staging) { slot = base / ca->n_frames; q_frame_new = base - slot * ca->n_frames; }
-          q_tile_new = ca->tile_order ? ca->tile_order[slot] : slot;
           const uint32_t tile = q_tile_new * ca->world + ca->rank;
           const uint32_t tx = tile % ca->tiles_x, ty = tile / ca->tiles_x;
           const uint32_t pu = tx * 8u + (lane & 7u), pv = ty * 8u + (lane >> 3);
@@ -769,6 +837,64 @@ __global__ __launch_bounds__(256) void rt_combine_frames_kernel(const rt_kargs a
   }
 }
 
+// SKY TILES ("sky tiles"): flags[j] = 1 when EVERY primary ray the pixels of this rank's j-th 8x8 tile can draw
+// is a certain miss of EVERY sphere in the literal arithmetic of hit_sphere (wgsl:200-231), so that the path kernel may
+// finish the tile without tracing. A sufficient condition, evaluated in double precision with margins far above the
+// f32 rounding of the literal code; a tile that fails it is simply traced.
+//   directions of the tile: d = c0 u + c1 (H - v) + c3 + (px dx, py dy, dz), u, v over the 8x8 pixels, px, py in [-.5, .5)
+//   (wgsl:85-94,174-180; c0, c1, c3 columns of pixel_to_world, delta = c0 - c1): a ball of radius rho around dc.
+//   Per sphere (centre c, radius r, seen from the origin o at distance L under the angle psi against dc), with
+//   S = |o|^2 + |c|^2 + r^2 and theta = asin(rho / |dc|):
+//   (i)  L^2 - r^2 > 2^-12 S: the origin is outside, by 4000 times the rounding of the literal `c`; and
+//   (A)  L^2 sin^2(min(psi, pi - psi) - theta) > r^2 + 2^-12 S: no line of the cone comes near the sphere, the exact
+//        discriminant is below -2^-12 a S and the literal one (within 54 2^-24 a S of it) is negative; or
+//   (B)  cos(psi - theta) < -2^-8: the sphere lies behind every ray, literal half_b > 0 and c > 0, both roots <= 0 <= tmin.
+//   Rays must be `tame` (no overflow / underflow in the literal code): |d|^2 in [2^-19, 2^19], |o|^2 <= 2^39, tame scene.
+__global__ __launch_bounds__(256) void rt_sky_tiles_kernel(const rt_kargs a, uint32_t* __restrict__ flags) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= a.my_tiles) return;
+  const uint32_t tile = j * a.world + a.rank;
+  const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+  const double c0[3] = {a.p2w[0], a.p2w[1], a.p2w[2]}, c1[3] = {a.p2w[4], a.p2w[5], a.p2w[6]}, c3[3] = {a.p2w[12], a.p2w[13], a.p2w[14]};
+  const double o[3] = {a.pos[0], a.pos[1], a.pos[2]};
+  const double H = (double)a.height;
+  const double um = 8.0 * tx + 3.5, vm = H - (8.0 * ty + 3.5);
+  double dc[3], n0 = 0, n1 = 0, n3 = 0, nd = 0, oo = 0;
+  for (int i = 0; i < 3; ++i) {
+    dc[i] = c0[i] * um + c1[i] * vm + c3[i];
+    n0 += c0[i] * c0[i]; n1 += c1[i] * c1[i]; n3 += c3[i] * c3[i];
+    nd += (c0[i] - c1[i]) * (c0[i] - c1[i]);
+    oo += o[i] * o[i];
+  }
+  dc[2] += c0[2] - c1[2];  // + 1.0 * pixel_delta.z
+  n0 = sqrt(n0); n1 = sqrt(n1); n3 = sqrt(n3); nd = sqrt(nd);
+  const double mag = n0 * (8.0 * tx + 9.0) + n1 * (H + 1.0) + n3 + nd;  // magnitude of the f32 terms that form d
+  const double rho = (3.5 * (n0 + n1) + 0.5 * (fabs(c0[0] - c1[0]) + fabs(c0[1] - c1[1]))) * (1.0 + 0x1p-20) + 0x1p-18 * mag;
+  const double ndc = sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]);
+  bool ok = a.p1_tame != 0u && rho < 0.25 * ndc && oo <= 0x1p39 && (ndc - rho) * (ndc - rho) >= 0x1p-19 && (ndc + rho) * (ndc + rho) <= 0x1p19;
+  if (ok) {  // also false for NaN / inf matrices
+    const double sin_t = rho / ndc, cos_t = sqrt(1.0 - sin_t * sin_t);
+    for (uint32_t i = 0; i < a.n_spheres; ++i) {
+      const rt_f32x4 sp = a.sph_shade[i];
+      const double c[3] = {sp.x, sp.y, sp.z}, r2 = (double)sp.w * sp.w;
+      const double v[3] = {c[0] - o[0], c[1] - o[1], c[2] - o[2]};
+      const double L2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+      const double m = 0x1p-12 * (oo + c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + r2);
+      bool miss = false;
+      if (L2 - r2 > m) {
+        const double cpsi = (v[0] * dc[0] + v[1] * dc[1] + v[2] * dc[2]) / (sqrt(L2) * ndc);
+        const double ac = fmin(fabs(cpsi), 1.0), sp1 = sqrt(1.0 - ac * ac);
+        const double sdiff = sp1 * cos_t - ac * sin_t;  // sin(min(psi, pi - psi) - theta)
+        const bool clear = sdiff > 0.0 && L2 * sdiff * sdiff > (r2 + m) * (1.0 + 0x1p-20);
+        const bool behind = cpsi * cos_t + sp1 * sin_t < -0x1p-8;  // cos(psi - theta)
+        miss = clear || behind;
+      }
+      if (!miss) { ok = false; break; }
+    }
+  }
+  flags[j] = ok ? 1u : 0u;
+}
+
 // Tile order for the next launch: counting sort of this launch's per-tile cost, dearest first.
 // One workgroup; order[] becomes a permutation of [0, n) whatever the costs are.
 __global__ __launch_bounds__(1024) void rt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n) {
@@ -831,6 +957,12 @@ hipError_t rt_launch_combine_frames(const rt_kargs& a, hipStream_t stream) {
   if (!a.staging || !a.frame_table || a.n_frames == 0 || a.cov_w == 0 || a.cov_h == 0) return hipErrorInvalidValue;
   const dim3 grid((a.cov_w + 63u) / 64u, (a.cov_h + 3u) / 4u), block(256);
   hipLaunchKernelGGL(rt_combine_frames_kernel, grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t rt_launch_sky_tiles(const rt_kargs& a, uint32_t* flags, hipStream_t stream) {
+  if (a.my_tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(rt_sky_tiles_kernel, dim3((a.my_tiles + 255u) / 256u), dim3(256), 0, stream, a, flags);
   return hipGetLastError();
 }
 

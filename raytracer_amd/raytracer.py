@@ -82,6 +82,12 @@ class Raytracer:
     def set_partition(self, rank, world):
         check(self._lib.rt_set_partition(self._h, rank, world))
 
+    def sky_tile_stats(self):
+        """(tiles the last pass finished without tracing, tiles of this context's partition)"""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        check(self._lib.rt_sky_tile_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def set_stream(self, hip_stream_handle):
         check(self._lib.rt_set_stream(self._h, C.c_void_p(hip_stream_handle)))
 

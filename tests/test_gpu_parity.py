@@ -525,3 +525,83 @@ def test_staged_batches_equal_pixel_sequential_batches_and_the_oracle(flags, mon
                 assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32)), (staged, rank, world)
             assert np.array_equal(rt.read_rgba8(), img.view_rgba8()), (staged, rank, world)
             rt.close()
+
+
+def _render_state(R, W, H, flags, spheres, mats, cam, frames, batched, rank=0, world=1):
+    rt = _run_gpu(R, W, H, flags, spheres, mats, cam, frames, batched=batched, rank=rank, world=world)
+    out = (rt.read_rng_state().copy(), rt.read_accum_f32().view(np.uint32).copy() if flags & O.ACCUM_F32 else None,
+           rt.read_rgba8().copy(), rt.sky_tile_stats())
+    rt.close()
+    return out
+
+
+SKY_CASES = [
+    # name, W, H, spp, frames, flags, scene, batched, (rank, world)
+    ("default_rgba8", 640, 368, 2, 3, 0, "default", False, (0, 1)),
+    ("default_f32_batch", 640, 368, 4, 3, O.ACCUM_F32, "default", True, (0, 1)),          # staged (tile, frame) units
+    ("default_sum_partition", 512, 288, 2, 2, O.ACCUM_F32 | O.COMBINE_SUM, "default", False, (1, 3)),
+    ("default_full_ragged", 500, 300, 1, 2, O.DISPATCH_FULL, "default", True, (0, 1)),     # 1 spp: pixel-sequential batch
+    ("checker_bunch20", 768, 432, 2, 2, O.SHADE_CHECKER | O.ACCUM_F32, "bunch20", False, (0, 1)),
+    ("bunch1024", 480, 272, 1, 2, 0, "bunch1024", False, (0, 1)),
+]
+
+
+@pytest.mark.parametrize("math", [0x0, 0x8], ids=["strict", "fast"])  # RT_MATH_STRICT, RT_MATH_FAST
+@pytest.mark.parametrize("name,W,H,spp,frames,flags,scene,batched,part", SKY_CASES, ids=[c[0] for c in SKY_CASES])
+def test_sky_tiles_change_nothing(name, W, H, spp, frames, flags, scene, batched, part, math, monkeypatch):
+    """Tiles whose primary rays provably miss every sphere are finished without tracing (rt_sky_tiles_kernel).
+    With RT_SKY_TILES=0 every tile is traced: image, float image and every RNG state must be identical, in both
+    arithmetic modes, for per-frame, pixel-sequential and staged launches, and under a tile partition."""
+    R = _rt()
+    spheres, mats = _scene(scene)
+    cam = scenes.camera_raw(W, H, spp=spp, frames=frames)
+    monkeypatch.setenv("RT_SKY_TILES", "1")
+    on = _render_state(R, W, H, flags | math, spheres, mats, cam, frames, batched, *part)
+    monkeypatch.setenv("RT_SKY_TILES", "0")
+    off = _render_state(R, W, H, flags | math, spheres, mats, cam, frames, batched, *part)
+    assert off[3] == (0, 0)
+    sky, tiles = on[3]
+    assert 0 < sky < tiles, (sky, tiles)
+    assert np.array_equal(on[0], off[0])
+    if flags & O.ACCUM_F32:
+        assert np.array_equal(on[1], off[1])
+    assert np.array_equal(on[2], off[2])
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_sky_tiles_fuzzed_cameras_and_scenes(seed, monkeypatch):
+    """The sky-tile bound must be conservative for any scene and camera: random scenes (tiny and huge scales, cameras
+    inside spheres, zero and negative radii) at a resolution where tiles are small enough to be sky."""
+    R = _rt()
+    rs = np.random.RandomState(5000 + seed)
+    spheres, mats, camkw = _fuzz_scene(rs)
+    W, H = 384, 224
+    flags = O.ACCUM_F32 | (O.SHADE_CHECKER if seed % 3 == 0 else 0) | (0x8 if seed % 4 == 3 else 0)
+    cam = scenes.camera_raw(W, H, spp=2, frames=2, **camkw)
+    monkeypatch.setenv("RT_SKY_TILES", "1")
+    on = _render_state(R, W, H, flags, spheres, mats, cam, 2, False)
+    monkeypatch.setenv("RT_SKY_TILES", "0")
+    off = _render_state(R, W, H, flags, spheres, mats, cam, 2, False)
+    assert np.array_equal(on[0], off[0]) and np.array_equal(on[1], off[1]), on[3]
+
+
+def test_sky_tiles_follow_the_camera_and_the_scene():
+    """The flags are recomputed when the camera or the scene changes (a stale flag would skip a visible sphere)."""
+    R = _rt()
+    W, H = 512, 288
+    spheres, mats = scenes.default_scene(1)
+    rt = R.Raytracer(W, H, O.ACCUM_F32)
+    rt.enable_rng_capture(True)
+    tb = O.time_bits_table(1)
+    seen = []
+    for look, scene in (((0.0, 0.0, -1.0), (spheres, mats)), ((0.0, 0.6, -1.0), (spheres, mats)), ((0.0, 0.0, -1.0), (spheres[:3], mats))):
+        rt.set_scene(*scene)
+        cam = scenes.camera_raw(W, H, spp=1, frames=4, look=look)
+        rt.clear(); rt.set_camera(cam); rt.set_time(int(tb[0])); rt.compute(); rt.sync()
+        img = O.OracleImage(W, H, O.ACCUM_F32)
+        O.render(img, scene[0], scene[1], cam, 0, 1)
+        assert np.array_equal(rt.read_rng_state(), img.rng)
+        assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
+        seen.append(rt.sky_tile_stats()[0])
+    rt.close()
+    assert len(set(seen)) == 3 and min(seen) > 0, seen

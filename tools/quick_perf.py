@@ -34,6 +34,8 @@ def run(name, W, H, spp, scene, shade, math, reps=3, accum=R.RT_ACCUM_F32):
     samples = c["N"]
     print(f"{name:28s} {'fast' if math else 'strict':6s} {ms:9.3f} ms  {samples/ms/1e6:8.2f} Gsamples/s  {c['R']/ms/1e6:8.2f} Grays/s  "
           f"{fl/ms/1e9:7.2f} TFLOP/s ({fl/ms/1e9/157.3*100:5.1f}% of 157.3)  rays/sample {c['R']/samples:.2f} tests/ray {c['T']/c['R']:.0f} occ_trace {c['R']/max(occ['slots_trace'],1):.3f} occ_rej {c['J']/max(occ['slots_reject'],1):.3f} cand/ray {c['D']/c['R']:.2f}", flush=True)
+    if hasattr(rt, "sky_tile_stats"):
+        print("      sky tiles %d of %d" % rt.sky_tile_stats(), flush=True)
     rt.close()
 
 if __name__ == "__main__":
