@@ -41,8 +41,22 @@ __device__ __forceinline__ float as_f32(uint32_t u) { return __builtin_bit_cast(
 __device__ __forceinline__ uint32_t as_u32(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 // raytrace_kernal.wgsl:265-275 (state update) — integer, bit-exact in every mode
+#ifndef RT_RNG_MAD64
+#define RT_RNG_MAD64 1
+#endif
 __device__ __forceinline__ uint32_t rng_step(uint32_t rng) {
+#if RT_RNG_MAD64
+  // rng * 18197 + 182489729 as ONE v_mad_u64_u32 (low half of the 64-bit result): 4.7 issue cycles against
+  // 4.35 + 3.1 for v_mul_lo_u32 + v_add_u32 (profiles/r1e_valu_ubench.txt). VOP3 reads one scalar operand at
+  // most, so the multiplier travels in a vector register (laundered, or the compiler folds it back into v_mul_lo).
+  uint32_t mulv = 18197u;
+  asm("" : "+v"(mulv));
+  unsigned long long wide, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(wide), "=s"(carry) : "v"(rng), "v"(mulv), "s"(182489729ull));
+  rng = (uint32_t)wide;
+#else
   rng = rng * 18197u + 182489729u;
+#endif
   rng ^= (rng << 15);
   rng ^= (rng >> 22);
   rng ^= (rng << 4);
@@ -126,9 +140,9 @@ __device__ __forceinline__ float div_core(float x, const rn_divisor& d) {
 // x / y for a caller that knows more than the operand ranges: `generic` marks the lanes whose operands may
 // leave the range div_core is correctly rounded for (they take the compiler's division), `any_generic` is the
 // wave-uniform "some lane does" - both computed once per ray instead of two compares per quotient.
-__device__ __forceinline__ float div_known(float x, const rn_divisor& d, bool generic, bool any_generic) {
+__device__ __forceinline__ float div_known(float x, const rn_divisor& d, bool generic, unsigned long long any_generic) {
   float q = div_core(x, d);
-  if (__builtin_expect(any_generic, 0)) {
+  if (__builtin_expect(any_generic != 0ull, 0)) {  // a ballot: stays in scalar registers, one s_cmp + branch
     if (generic) q = x / d.y;
   }
   return q;
@@ -595,7 +609,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
         // all inside div_core's range (a +0 component gives +0 like the IEEE quotient); p = 0 (0/0) goes the generic way
         const rn_divisor len = make_divisor(sqrt_rn(gl2));
         const bool zero_len = !(gl2 >= 0x1p-50f);
-        const bool any_zero_len = __ballot(zero_len) != 0ull;
+        const unsigned long long any_zero_len = __ballot(zero_len);
         const float ux = div_known(gqx, len, zero_len, any_zero_len), uy = div_known(gqy, len, zero_len, any_zero_len),
                     uz = div_known(gqz, len, zero_len, any_zero_len);
         dx = dx + ux; dy = dy + uy; dz = dz + uz;
@@ -644,7 +658,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_karg
       // is below div_core's upper limit, and a numerator under its lower limit 2^-60 gives |quotient| < 2^-38 both
       // exactly and from div_core - far below RT_RAY_TMIN, where only the comparison `root <= tmin` is used.
       // Untamed rays take the compiler's division.
-      const bool any_untame = __ballot(!tame) != 0ull;
+      const unsigned long long any_untame = __ballot(!tame);
       const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
       if (COUNT) { c_R++; c_T += n_spheres; }
       RT_PROF_END(1);
