@@ -160,7 +160,11 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.reject_tries = a.n_spheres <= 8u ? (strict_math ? 3u : 2u) : (a.n_spheres <= 64u ? 3u : 64u);
   if (ctx->reject_tries > 0) a.reject_tries = (uint32_t)ctx->reject_tries;
   // Persistent launch: enough single-wave workgroups to fill every SIMD, never more than tiles.
-  const uint32_t wpc = ctx->waves_per_cu > 0 ? (uint32_t)ctx->waves_per_cu : 24u;  // 6 waves per SIMD are resident (<= 80 VGPRs)
+  // 6 waves per SIMD are resident (<= 80 VGPRs); the small-scene variants fit 7 (<= 72 VGPRs), which pays when a
+  // rank has enough tiles to keep 28 waves per CU busy to the end (C3: -1.5 %; C2 with 5 tiles per wave: +4 %, so not there)
+  uint32_t wpc = 24u;
+  if (!ctx->counting && a.n_spheres <= 128u && (uint64_t)my_tiles >= 16ull * 28ull * (uint64_t)ctx->compute_units) wpc = 28u;
+  if (ctx->waves_per_cu > 0) wpc = (uint32_t)ctx->waves_per_cu;
   const uint64_t resident = (uint64_t)ctx->compute_units * wpc;
   // STAGED LAUNCH (batches only): a pixel is sequential, so with few tiles per wave the launch would end on
   // the waves that drew the dearest pixels - for all n_frames of them. When a rank has fewer than

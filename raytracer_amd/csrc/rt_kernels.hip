@@ -277,7 +277,9 @@ template <bool STRICT, bool COUNT, bool CULL>
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 6  // keeps the production variants at <= 80 VGPRs = 6 waves per SIMD (measured: C3 strict -2.7 %)
 #endif
-__global__ __launch_bounds__(64, RT_MIN_WAVES) void rt_path_kernel(const rt_kargs a) {
+// The small-scene variants (strict + cull; fast needs 70 VGPRs anyway) are held to 72 VGPRs = 7 waves per SIMD: big
+// images of small scenes gain 1-2 % from the seventh wave (profiles/r1e_ab_waves.log), the 1024-sphere scene loses 3 %.
+__global__ __launch_bounds__(64, (CULL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_path_kernel(const rt_kargs a) {
   const uint32_t lane = threadIdx.x;
   const bool checker = (a.flags & RT_SHADE_CHECKER) != 0;
   const bool accum_f32 = (a.flags & RT_ACCUM_F32) != 0;
