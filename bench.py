@@ -6,7 +6,9 @@
 
 A STEP is one compute pass (`rt_compute`, reference Raytracer::compute, src/raytracing.rs:178-200)
 over the whole image of the workload BASELINE.json's metric is quoted on: C3 = 3840x2160, 64 spp,
-glowing-checkers scene (random_bunch(20)). With N GPUs the progressive render is split by disjoint
+glowing-checkers scene (random_bunch(20)). rt_compute, like the reference's compute, records the pass;
+the library runs up to 8 recorded passes as one batched launch when the caller synchronises (bit-identical
+to one launch per pass; `per_pass_launches` in the JSON line is the same measurement with RT_DEFER_FRAMES=1). With N GPUs the progressive render is split by disjoint
 per-frame sample sets (BASELINE north_star's second partition): in step i rank r renders frame
 i*N + r of the whole 4K image into a float sum, so per-GPU work is fixed ("weak" scaling) and a step
 of the job is N frames; the per-GPU sums are combined by ONE RCCL sum-reduce at the end of the
@@ -21,7 +23,7 @@ resident in HBM, RT_MATH_STRICT (the mode that is bit-identical to the oracle). 
   cpu_baseline the oracle (scalar C port, OpenMP) timed on this box's host cores on a bounded
                tile sample of the same frame (rank 0, N = 1 only).
   fast_math    the same measurement in RT_MATH_FAST (image within tolerance, not bit-exact).
-  batched_render the same frames as one rt_render_frames launch (N = 1 only; staged (tile, frame) units).
+  per_pass_launches the same measurement with one kernel launch per pass (RT_DEFER_FRAMES=1; N = 1 only).
 """
 import argparse
 import json
@@ -128,31 +130,6 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
             "sky_flops_per_launch": sky_tiles * 64 * spp * (8 + 6 + 17 * int(cfg["spheres"].shape[0]) + 15)}
 
 
-def measure_batched(R, cfg, flags, frames, device):
-    """The same frames submitted as ONE rt_render_frames batch (what App::run does): (tile, frame) work units,
-    so the launch does not end on one pixel's whole sample loop. Same arithmetic, bit-identical images."""
-    from raytracer_amd import host
-
-    W, H, spp = cfg["width"], cfg["height"], cfg["spp"]
-    rt = R.Raytracer(W, H, flags, device=device)
-    rt.set_scene(cfg["spheres"], cfg["materials"])
-    tb = host.time_table(2 * frames)
-    cam = host.camera_raw(W, H, spp=spp, frames=2 * frames)
-    rt.set_camera(cam)
-    rt.render_frames(tb[:frames])  # warm-up batch (also measures the tile order)
-    rt.sync()
-    t0 = time.perf_counter()
-    rt.render_frames(tb[frames:])
-    rt.sync()
-    seconds = time.perf_counter() - t0
-    rt.close()
-    cov_w = W if flags & R.RT_DISPATCH_FULL else (W // 16) * 16
-    cov_h = H if flags & R.RT_DISPATCH_FULL else (H // 16) * 16
-    return {"value": cov_w * cov_h * spp * frames / seconds, "unit": "samples/s", "frames_per_launch": frames,
-            "ms_per_frame": seconds * 1e3 / frames,
-            "note": "one rt_render_frames launch; bit-identical to the per-frame passes that `value` times"}
-
-
 def cpu_baseline(cfg, flags, target_seconds):
     """The oracle on this box's host cores, on every `world`-th 8x8 tile of the same frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -243,32 +220,45 @@ def main():
         return m
 
     m = run(args.math)
-    extras = None
+    extras = per_pass = None
     if not args.no_extras and world == 1:
         extras = run("fast" if args.math == "strict" else "strict")
+        os.environ["RT_DEFER_FRAMES"] = "1"  # read by rt_create
+        per_pass = run(args.math)
+        del os.environ["RT_DEFER_FRAMES"]
 
     if rank == 0:
-        def traffic(math):
+        def traffic(math, frames_per_launch):
             # HBM bytes per launch from the committed PMC pass of this same command (profiles/), or null
             path = os.path.join(ROOT, "profiles", f"traffic_{args.config}_{math}.json")
             try:
-                return json.load(open(path))["bytes_per_launch"] if world == 1 else None
+                t = json.load(open(path))
+                return t["bytes_per_launch"] if world == 1 and t.get("frames_per_launch", 1) == frames_per_launch else None
             except (OSError, ValueError, KeyError):
                 return None
 
         def roof(mm, math=None):
-            avg_ms = mm["kernel_ms"] / max(mm["launches"], 1)
-            achieved = mm["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
-            traced = (mm["flops_per_launch"] - mm["sky_flops_per_launch"]) / (avg_ms * 1e-3) / 1e12
+            launches = max(mm["launches"], 1)
+            fpl = args.steps / launches  # passes (frames) per kernel launch
+            avg_ms = mm["kernel_ms"] / launches
+            achieved = mm["flops_per_launch"] * fpl / (avg_ms * 1e-3) / 1e12
+            traced = (mm["flops_per_launch"] - mm["sky_flops_per_launch"]) * fpl / (avg_ms * 1e-3) / 1e12
+            px = cfg["width"] // 16 * 16 * (cfg["height"] // 16 * 16)
+            f32 = bool(base_flags & R.RT_ACCUM_F32)
+            # path kernel: the image read + written once per launch, or - in a staged batch (the library's rule: several
+            # passes, >= 4 spp, fewer than 32 tiles per resident wave) - 16 B per pixel and pass written to the staging buffer
+            tiles = px // 64
+            staged = fpl > 1 and cfg["spp"] >= 4 and tiles < 32 * 24 * mm["device"]["compute_units"]
+            alg_traffic = px * (16 * fpl if staged else (32 if f32 else 8))
             return {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
                     # the same with the samples the sky-tile bound resolved taken out of the numerator: what the hit loop itself sustains
                     "achieved_traced_only": round(traced, 3), "frac_traced_only": round(traced / FP32_VALU_PEAK_TFLOPS, 4),
                     "sky_tiles": mm["sky_tiles"], "tiles": mm["my_tiles"],
-                    "traffic": traffic(math or args.math),
-                    "traffic_algorithmic": cfg["width"] // 16 * 16 * (cfg["height"] // 16 * 16) * (32 if base_flags & R.RT_ACCUM_F32 else 8),
-                    "kernel": "rt_path_kernel", "avg_launch_ms": round(avg_ms, 4),
-                    "algorithmic_flops_per_launch": mm["flops_per_launch"],
+                    "traffic": traffic(math or args.math, fpl),
+                    "traffic_algorithmic": int(alg_traffic),
+                    "kernel": "rt_path_kernel", "avg_launch_ms": round(avg_ms, 4), "launches": launches, "passes_per_launch": fpl,
+                    "algorithmic_flops_per_launch": int(mm["flops_per_launch"] * fpl),
                     "note": "FP32 vector roofline (no MFMA: no dense contraction); peak is the packed-FMA figure, "
                             "78.6 TFLOP/s for non-packed FMA; FLOPs = SURVEY §8d formula over device event counters "
                             "of one launch" + (" of rank 0's tiles" if world > 1 else "") +
@@ -304,9 +294,10 @@ def main():
                                     "ms_per_step": extras["seconds"] * 1e3 / args.steps, "roofline": roof(extras, other),
                                     "parity": "image within PSNR >= 40 dB of strict; RNG function bit-exact" if other == "fast"
                                     else "bit-identical to the oracle"}
-        if world == 1 and not args.no_extras:
-            out["batched_render"] = measure_batched(R, cfg, base_flags | (R.RT_MATH_FAST if args.math == "fast" else 0),
-                                                    max(args.steps, 2), local_rank)
+        if per_pass is not None:
+            out["per_pass_launches"] = {"value": per_pass["samples_per_step"] * args.steps / per_pass["seconds"], "unit": "samples/s",
+                                        "ms_per_step": per_pass["seconds"] * 1e3 / args.steps, "roofline": roof(per_pass),
+                                        "note": "RT_DEFER_FRAMES=1: every rt_compute is its own kernel launch (each with its own tail)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, base_flags, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -82,6 +82,10 @@ struct rt_ctx {
   rt_f32x4* staging = nullptr;
   size_t staging_bytes = 0;
   int use_staging = 1;        // env RT_STAGED_FRAMES=0 keeps batched launches pixel-sequential
+  // deferred passes: rt_compute records (frame, time bits); the passes run as ONE batched launch when `defer_max` of
+  // them wait or when any call observes or changes what they depend on (flush_pending)
+  std::vector<uint32_t> pend_frames, pend_time;
+  int defer_max = 8;          // env RT_DEFER_FRAMES (<= 1: every rt_compute launches at once)
   // per-launch timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -197,7 +201,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // rejected by the kernel's own guard; every pixel index is < width*height by construction of cov_*
   if (a.cov_w > a.width || a.cov_h > a.height) return fail(RT_ERR_INVALID, "covered area exceeds the image");
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->timing) {
+  if (ctx->timing) {  // the events bracket the path kernel alone (what rocprofv3 reports as its duration)
     if (ctx->events_used == ctx->events.size()) {
       RT_HIP(hipEventCreate(&e0));
       RT_HIP(hipEventCreate(&e1));
@@ -206,7 +210,6 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     e0 = ctx->events[ctx->events_used].first;
     e1 = ctx->events[ctx->events_used].second;
     ctx->events_used++;
-    RT_HIP(hipEventRecord(e0, ctx->stream));
   }
   const bool strict = (ctx->flags & RT_MATH_FAST) == 0;
   // Cost-ordered queue (only worth it when there are more tiles than waves): hand tiles out dearest
@@ -256,9 +259,10 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     a.sky_flags = ctx->sky_flags;
   }
   RT_HIP(hipMemsetAsync(ctx->queue, 0, sizeof(uint32_t), ctx->stream));
+  if (ctx->timing) RT_HIP(hipEventRecord(e0, ctx->stream));
   RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, ctx->stream));
-  if (a.staging) RT_HIP(rt_launch_combine_frames(a, ctx->stream));
   if (ctx->timing) RT_HIP(hipEventRecord(e1, ctx->stream));
+  if (a.staging) RT_HIP(rt_launch_combine_frames(a, ctx->stream));
   if (measure) {
     RT_HIP(rt_launch_tile_order(ctx->tile_cost, ctx->tile_order, my_tiles, ctx->stream));
     ctx->have_order = true;
@@ -266,6 +270,54 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   }
   return RT_OK;
 }
+
+// n passes (frames[i] = CameraRaw.current_frame of pass i, time_bits[i] its time uniform) as one launch
+int launch_batch(rt_ctx* ctx, const uint32_t* frames, const uint32_t* time_bits, uint32_t n) {
+  if (n == 0) return RT_OK;
+  if (n == 1) return launch(ctx, frames[0], 1, time_bits[0], nullptr);
+  if (ctx->time_pending) {  // the staging buffer may still be in flight from the previous batch
+    RT_HIP(hipEventSynchronize(ctx->time_copied));
+    ctx->time_pending = false;
+  }
+  if (n > ctx->time_cap) {
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->time_dev);
+    if (ctx->time_host) (void)hipHostFree(ctx->time_host);
+    ctx->time_dev = nullptr;
+    ctx->time_host = nullptr;
+    ctx->time_cap = 0;
+    size_t cap = 256;
+    while (cap < n) cap *= 2;
+    RT_HIP(hipMalloc((void**)&ctx->time_dev, cap * sizeof(uint2)));
+    RT_HIP(hipHostMalloc((void**)&ctx->time_host, cap * sizeof(uint2), hipHostMallocDefault));
+    ctx->time_cap = cap;
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    const float cw = frame_cw(frames[i]);
+    uint32_t cw_bits;
+    std::memcpy(&cw_bits, &cw, 4);
+    ctx->time_host[i] = make_uint2(time_bits[i] * 87189u + 189273u, cw_bits);
+  }
+  RT_HIP(hipMemcpyAsync(ctx->time_dev, ctx->time_host, n * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+  RT_HIP(hipEventRecord(ctx->time_copied, ctx->stream));
+  ctx->time_pending = true;
+  return launch(ctx, frames[0], n, time_bits[0], ctx->time_dev);
+}
+
+// Launches the passes rt_compute has recorded. Called by every entry point that observes the image, the counters or
+// the timing, or that changes something a recorded pass depends on; an error of the launch is that call's error.
+int flush_pending(rt_ctx* ctx) {
+  if (ctx->pend_frames.empty()) return RT_OK;
+  std::vector<uint32_t> frames, bits;
+  frames.swap(ctx->pend_frames);
+  bits.swap(ctx->pend_time);
+  return launch_batch(ctx, frames.data(), bits.data(), (uint32_t)frames.size());
+}
+
+#define RT_FLUSH(ctx)                          \
+  do {                                         \
+    if (int rc__ = flush_pending(ctx)) return rc__; \
+  } while (0)
 
 }  // namespace
 
@@ -311,6 +363,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e4 = std::getenv("RT_TILE_ORDER")) c->use_order = std::atoi(e4);
   if (const char* e5 = std::getenv("RT_STAGED_FRAMES")) c->use_staging = std::atoi(e5);
   if (const char* e6 = std::getenv("RT_SKY_TILES")) c->use_sky = std::atoi(e6);
+  if (const char* e7 = std::getenv("RT_DEFER_FRAMES")) c->defer_max = std::atoi(e7);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
   if (e == hipSuccess) {
     c->stream = c->own_stream;
@@ -330,7 +383,10 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
 void rt_destroy(rt_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream) {
+    (void)flush_pending(c);  // recorded passes run, as they did when rt_compute launched them itself
+    (void)hipStreamSynchronize(c->stream);
+  }
   for (auto& ev : c->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
@@ -358,6 +414,7 @@ void rt_destroy(rt_ctx* c) {
 int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, const rt_material* materials,
                  uint32_t n_materials) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   if (!spheres || !materials || n_spheres == 0 || n_materials == 0) return fail(RT_ERR_INVALID, "empty scene");
   if (n_spheres > (1u << 24)) return fail(RT_ERR_INVALID, "too many spheres");
   // phase-1 constants in sphere pairs {cx0,cx1, cy0,cy1, cz0,cz1, K'0,K'1}; the scene is padded to a multiple
@@ -422,6 +479,12 @@ int rt_set_camera(rt_ctx* ctx, const rt_camera_raw* camera) {
   if (!camera) return fail(RT_ERR_INVALID, "camera is null");
   if (camera->samples_per_pixel == 0)
     return fail(RT_ERR_INVALID, "samples_per_pixel must be >= 1 (the reference clamps it to [1,256], camera.rs:136-137)");
+  // recorded passes share one camera: anything but current_frame changing ends the batch
+  if (ctx->have_camera && !ctx->pend_frames.empty()) {
+    rt_camera_raw a = ctx->camera, b = *camera;
+    a.current_frame = b.current_frame = 0;
+    if (std::memcmp(&a, &b, sizeof a) != 0) RT_FLUSH(ctx);
+  }
   // a moved camera changes which tiles are dear: measure the per-tile cost again
   if (!ctx->have_camera || std::memcmp(ctx->camera.pixel_to_world, camera->pixel_to_world, sizeof camera->pixel_to_world) != 0 ||
       std::memcmp(ctx->camera.pos, camera->pos, sizeof camera->pos) != 0) {
@@ -445,6 +508,15 @@ int rt_compute(rt_ctx* ctx) {
   if (!ctx->have_scene || !ctx->have_camera || !ctx->have_time)
     return fail(RT_ERR_STATE, "rt_compute before rt_set_scene / rt_set_camera / rt_set_time");
   if (ctx->camera.current_frame >= ctx->camera.frames_to_render) return RT_OK;  // wgsl:76
+  // Like Raytracer::compute, which only records the dispatch (raytracing.rs:178-200; app.rs:111 submits): the pass is
+  // recorded, and up to defer_max recorded passes run as one batched launch (staged (tile, frame) units where that
+  // pays) - bit-identical to launching them one by one, without each launch's tail. Counting launches stay single.
+  if (ctx->defer_max > 1 && !ctx->counting) {
+    ctx->pend_frames.push_back(ctx->camera.current_frame);
+    ctx->pend_time.push_back(ctx->time_bits);
+    if ((int)ctx->pend_frames.size() >= ctx->defer_max) RT_FLUSH(ctx);
+    return RT_OK;
+  }
   return launch(ctx, ctx->camera.current_frame, 1, ctx->time_bits, nullptr);
 }
 
@@ -454,37 +526,12 @@ int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames) 
   if (!time_bits || n_frames == 0) return fail(RT_ERR_INVALID, "empty time table");
   const uint32_t cur = ctx->camera.current_frame, total = ctx->camera.frames_to_render;
   const uint32_t live = cur < total ? (n_frames < total - cur ? n_frames : total - cur) : 0u;  // rest are no-ops (wgsl:76)
+  RT_FLUSH(ctx);
   int rc = RT_OK;
-  if (live == 1) {
-    rc = launch(ctx, cur, 1, time_bits[0], nullptr);
-  } else if (live > 1) {
-    if (ctx->time_pending) {  // the staging buffer may still be in flight from the previous batch
-      RT_HIP(hipEventSynchronize(ctx->time_copied));
-      ctx->time_pending = false;
-    }
-    if (live > ctx->time_cap) {
-      RT_HIP(hipStreamSynchronize(ctx->stream));
-      (void)hipFree(ctx->time_dev);
-      if (ctx->time_host) (void)hipHostFree(ctx->time_host);
-      ctx->time_dev = nullptr;
-      ctx->time_host = nullptr;
-      ctx->time_cap = 0;
-      size_t cap = 256;
-      while (cap < live) cap *= 2;
-      RT_HIP(hipMalloc((void**)&ctx->time_dev, cap * sizeof(uint2)));
-      RT_HIP(hipHostMalloc((void**)&ctx->time_host, cap * sizeof(uint2), hipHostMallocDefault));
-      ctx->time_cap = cap;
-    }
-    for (uint32_t i = 0; i < live; ++i) {
-      const float cw = frame_cw(cur + i);
-      uint32_t cw_bits;
-      std::memcpy(&cw_bits, &cw, 4);
-      ctx->time_host[i] = make_uint2(time_bits[i] * 87189u + 189273u, cw_bits);
-    }
-    RT_HIP(hipMemcpyAsync(ctx->time_dev, ctx->time_host, live * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(hipEventRecord(ctx->time_copied, ctx->stream));
-    ctx->time_pending = true;
-    rc = launch(ctx, cur, live, time_bits[0], ctx->time_dev);
+  if (live > 0) {
+    std::vector<uint32_t> frames(live);
+    for (uint32_t i = 0; i < live; ++i) frames[i] = cur + i;
+    rc = launch_batch(ctx, frames.data(), time_bits, live);
   }
   if (rc != RT_OK) return rc;
   ctx->camera.current_frame = cur + n_frames;  // Camera::increase_frame once per redraw (camera.rs:253)
@@ -495,12 +542,14 @@ int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames) 
 
 int rt_sync(rt_ctx* ctx) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   RT_HIP(hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
 
 int rt_read_rgba8(rt_ctx* ctx, void* dst, size_t bytes) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   const size_t px = (size_t)ctx->width * ctx->height;
   if (!dst || bytes != px * 4u) return fail(RT_ERR_INVALID, "rt_read_rgba8: need width*height*4 bytes");
   const void* src = ctx->accum;
@@ -516,6 +565,7 @@ int rt_read_rgba8(rt_ctx* ctx, void* dst, size_t bytes) {
 
 int rt_read_accum_f32(rt_ctx* ctx, void* dst, size_t bytes) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   if (!(ctx->flags & RT_ACCUM_F32)) return fail(RT_ERR_STATE, "rt_read_accum_f32 on an RT_ACCUM_RGBA8 context");
   if (!dst || bytes != ctx->accum_bytes) return fail(RT_ERR_INVALID, "rt_read_accum_f32: need width*height*16 bytes");
   RT_HIP(hipMemcpyAsync(dst, ctx->accum, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -525,6 +575,7 @@ int rt_read_accum_f32(rt_ctx* ctx, void* dst, size_t bytes) {
 
 int rt_write_image(rt_ctx* ctx, const void* src, size_t bytes) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   if (!src || bytes != ctx->accum_bytes) return fail(RT_ERR_INVALID, "rt_write_image: need exactly the image size of this context");
   RT_HIP(hipMemcpyAsync(ctx->accum, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   RT_HIP(hipStreamSynchronize(ctx->stream));
@@ -533,6 +584,7 @@ int rt_write_image(rt_ctx* ctx, const void* src, size_t bytes) {
 
 int rt_enable_rng_capture(rt_ctx* ctx, int enable) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   if (enable && !ctx->rng) {
     const size_t bytes = (size_t)ctx->width * ctx->height * sizeof(uint32_t);
     RT_HIP(hipMalloc((void**)&ctx->rng, bytes));
@@ -544,6 +596,7 @@ int rt_enable_rng_capture(rt_ctx* ctx, int enable) {
 
 int rt_read_rng_state(rt_ctx* ctx, void* dst, size_t bytes) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   if (!ctx->rng) return fail(RT_ERR_STATE, "rt_read_rng_state before rt_enable_rng_capture");
   if (!dst || bytes != (size_t)ctx->width * ctx->height * 4u) return fail(RT_ERR_INVALID, "rt_read_rng_state: need width*height*4 bytes");
   RT_HIP(hipMemcpyAsync(dst, ctx->rng, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -553,12 +606,14 @@ int rt_read_rng_state(rt_ctx* ctx, void* dst, size_t bytes) {
 
 int rt_enable_counters(rt_ctx* ctx, int enable) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   ctx->counting = enable != 0;
   return RT_OK;
 }
 
 int rt_get_counters(rt_ctx* ctx, rt_counters* out) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   if (!out) return fail(RT_ERR_INVALID, "out is null");
   unsigned long long h[14];
   RT_HIP(hipMemcpyAsync(h, ctx->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -571,12 +626,14 @@ int rt_get_counters(rt_ctx* ctx, rt_counters* out) {
 
 int rt_reset_counters(rt_ctx* ctx) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   RT_HIP(hipMemsetAsync(ctx->counters, 0, 14 * sizeof(unsigned long long), ctx->stream));
   return RT_OK;
 }
 
 int rt_set_partition(rt_ctx* ctx, uint32_t rank, uint32_t world) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   if (world == 0 || rank >= world) return fail(RT_ERR_INVALID, "need rank < world");
   ctx->rank = rank;
   ctx->world = world;
@@ -585,6 +642,7 @@ int rt_set_partition(rt_ctx* ctx, uint32_t rank, uint32_t world) {
 
 int rt_sky_tile_stats(rt_ctx* ctx, uint32_t* sky_tiles, uint32_t* tiles) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   if (!sky_tiles || !tiles) return fail(RT_ERR_INVALID, "null out pointer");
   *sky_tiles = *tiles = 0;
   RT_HIP(hipStreamSynchronize(ctx->stream));
@@ -608,6 +666,7 @@ int rt_accum_device_ptr(rt_ctx* ctx, void** dptr, size_t* bytes) {
 
 int rt_bind_accum(rt_ctx* ctx, void* dptr, size_t bytes) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   if (dptr && bytes != ctx->accum_bytes) return fail(RT_ERR_INVALID, "rt_bind_accum: size must equal the image size");
   if (dptr && (reinterpret_cast<uintptr_t>(dptr) & 15u)) return fail(RT_ERR_INVALID, "rt_bind_accum: need 16-byte alignment");
   RT_HIP(hipStreamSynchronize(ctx->stream));
@@ -617,6 +676,7 @@ int rt_bind_accum(rt_ctx* ctx, void* dptr, size_t bytes) {
 
 int rt_set_stream(rt_ctx* ctx, void* hip_stream) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   RT_HIP(hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
   return RT_OK;
@@ -624,6 +684,7 @@ int rt_set_stream(rt_ctx* ctx, void* hip_stream) {
 
 int rt_clear(rt_ctx* ctx) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   RT_HIP(hipMemsetAsync(ctx->accum, 0, ctx->accum_bytes, ctx->stream));
   if (ctx->rng) RT_HIP(hipMemsetAsync(ctx->rng, 0, (size_t)ctx->width * ctx->height * 4u, ctx->stream));
   return RT_OK;
@@ -631,12 +692,14 @@ int rt_clear(rt_ctx* ctx) {
 
 int rt_enable_timing(rt_ctx* ctx, int enable) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   ctx->timing = enable != 0;
   return RT_OK;
 }
 
 int rt_timing_reset(rt_ctx* ctx) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   RT_HIP(hipStreamSynchronize(ctx->stream));
   ctx->events_used = 0;
   return RT_OK;
@@ -644,6 +707,7 @@ int rt_timing_reset(rt_ctx* ctx) {
 
 int rt_timing_get(rt_ctx* ctx, double* total_ms, uint32_t* launches) {
   if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);
   if (!total_ms || !launches) return fail(RT_ERR_INVALID, "null out pointer");
   RT_HIP(hipStreamSynchronize(ctx->stream));
   double sum = 0.0;

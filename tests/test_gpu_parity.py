@@ -605,3 +605,71 @@ def test_sky_tiles_follow_the_camera_and_the_scene():
         seen.append(rt.sky_tile_stats()[0])
     rt.close()
     assert len(set(seen)) == 3 and min(seen) > 0, seen
+
+
+@pytest.mark.parametrize("flags", [0, O.ACCUM_F32, O.ACCUM_F32 | O.COMBINE_SUM], ids=["rgba8", "f32", "f32_sum"])
+def test_deferred_passes_equal_single_launches_and_the_oracle(flags, monkeypatch):
+    """rt_compute records a pass; up to RT_DEFER_FRAMES (default 8) recorded passes run as one batched launch when
+    the caller synchronises or changes what they depend on. 11 passes (8 + 3), non-consecutive frame indices, a new
+    spp after pass 4 and a new scene after pass 7 must give the oracle's image and RNG states, as RT_DEFER_FRAMES=1 does."""
+    R = _rt()
+    W, H, frames = 200, 120, 11
+    scene_a, scene_b = scenes.default_scene(1), scenes.random_bunch(6, 3, 9)
+    tb = O.time_bits_table(frames)
+    frame_ix = [0, 1, 2, 3, 5, 6, 7, 9, 10, 11, 12]  # a frame-set split skips indices
+
+    def plan(f):
+        return (2 if f < 4 else 3), (scene_a if f < 7 else scene_b)
+
+    img = O.OracleImage(W, H, flags)
+    for f in range(frames):
+        spp, (sp, mt) = plan(f)
+        cam = scenes.camera_raw(W, H, spp=spp, frames=64, current_frame=frame_ix[f])
+        O.compute(img, sp, mt, cam, int(tb[f]))
+    results = []
+    for defer in ("8", "1"):
+        monkeypatch.setenv("RT_DEFER_FRAMES", defer)
+        rt = R.Raytracer(W, H, flags)
+        rt.enable_rng_capture(True)
+        last_scene = None
+        for f in range(frames):
+            spp, sc = plan(f)
+            if sc is not last_scene:
+                rt.set_scene(*sc)
+                last_scene = sc
+            rt.set_time(int(tb[f]))
+            rt.set_camera(scenes.camera_raw(W, H, spp=spp, frames=64, current_frame=frame_ix[f]))
+            rt.compute()
+        rt.sync()
+        results.append((rt.read_rng_state().copy(), rt.read_rgba8().copy(),
+                        rt.read_accum_f32().view(np.uint32).copy() if flags & O.ACCUM_F32 else None))
+        rt.close()
+    for rng, rgba, acc in results:
+        assert np.array_equal(rng, img.rng)
+        assert np.array_equal(rgba, img.view_rgba8())
+        if flags & O.ACCUM_F32:
+            assert np.array_equal(acc, img.accum.view(np.uint32))
+
+
+def test_deferred_passes_are_flushed_by_observers():
+    """clear(), a partition change and reads between recorded passes act on the passes recorded before them."""
+    R = _rt()
+    W, H = 96, 64
+    sp, mt = scenes.default_scene(1)
+    tb = O.time_bits_table(4)
+    rt = R.Raytracer(W, H, O.ACCUM_F32)
+    rt.set_scene(sp, mt)
+    img = O.OracleImage(W, H, O.ACCUM_F32)
+    def one(f, rank, world):
+        cam = scenes.camera_raw(W, H, spp=2, frames=8, current_frame=f)
+        rt.set_time(int(tb[f])); rt.set_camera(cam); rt.compute()
+        O.compute(img, sp, mt, cam, int(tb[f]), rank=rank, world=world)
+    one(0, 0, 1)
+    rt.clear()                      # wipes the image AFTER pass 0 ran
+    img.accum[:] = 0
+    one(1, 0, 1)
+    rt.set_partition(1, 2)          # pass 1 covered every tile, pass 2 and 3 only rank 1's
+    one(2, 1, 2)
+    one(3, 1, 2)
+    assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
+    rt.close()

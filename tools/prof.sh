@@ -5,7 +5,9 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-cmd="bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras $*"
+# 8 + 8 passes: the library runs them as two 8-pass launches (RT_DEFER_FRAMES), like the default bench command
+cmd="bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-extras $*"
+export PROF_FRAMES_PER_LAUNCH=${RT_DEFER_FRAMES:-8}
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $cmd > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS" \
