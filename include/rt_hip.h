@@ -53,7 +53,14 @@ int rt_set_time(rt_ctx* ctx, uint32_t time_bits);
 /* Raytracer::compute (raytracing.rs:178-200): one compute pass with the current camera and time —
  * trace samples_per_pixel paths per covered pixel, fold into the accumulation image; the
  * color_buffer -> color_cache copy is implicit (one in-place image). Asynchronous. Does nothing
- * when camera.current_frame >= camera.frames_to_render (raytrace_kernal.wgsl:76). */
+ * when camera.current_frame >= camera.frames_to_render (raytrace_kernal.wgsl:76).
+ * Like the reference's compute, which records the dispatch into a command encoder that App::render submits
+ * (app.rs:106-111), rt_compute RECORDS the pass (camera, time). Recorded passes run - as one batched launch of up to
+ * 8 passes, bit-identical to one launch per pass - when 8 wait or at the next call that observes the image, the
+ * counters or the timing (rt_sync, rt_read_*, rt_get_counters, rt_timing_get, ...) or that changes what a recorded
+ * pass depends on (scene, camera other than current_frame, partition, stream, bound image, rt_clear, rt_write_image);
+ * a launch failure is reported by that call. RT_DEFER_FRAMES=1 in the environment (read by rt_create) launches every
+ * pass at once. Passes run under rt_enable_counters launch at once, one by one. */
 int rt_compute(rt_ctx* ctx);
 
 /* Batched form of the App::update/App::render loop (app.rs:93-116) for `n_frames` redraws in ONE
