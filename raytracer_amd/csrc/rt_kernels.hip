@@ -592,7 +592,10 @@ __global__ __launch_bounds__(64, (CULL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_pa
       }
     }
     if (COUNT) c_wr++;
-    for (uint32_t round = 1; round < a.reject_tries && __ballot(state == ST_NEED_DIR); ++round) {
+#ifndef RT_ROUND_MIN_LANES
+#define RT_ROUND_MIN_LANES 1u  // a further round runs while at least this many lanes still need a direction
+#endif
+    for (uint32_t round = 1; round < a.reject_tries && (uint32_t)__popcll(__ballot(state == ST_NEED_DIR)) >= RT_ROUND_MIN_LANES; ++round) {
       if (COUNT) c_wr++;
       if (state == ST_NEED_DIR) {
         uint32_t s0, s1, s2;
