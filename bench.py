@@ -187,6 +187,12 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
+    # stdout carries exactly ONE line, the JSON: libraries that print banners to fd 1 (RCCL prints its version
+    # there when it initialises) are sent to stderr, and the line goes out through a saved copy of the descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -300,7 +306,7 @@ def main():
                                         "note": "RT_DEFER_FRAMES=1: every rt_compute is its own kernel launch (each with its own tail)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, base_flags, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if use_dist:
         dist.barrier()
