@@ -21,6 +21,9 @@
 //  * BOUNDED REJECTION SAMPLING. random_in_unit_sphere (p = pi/6) runs at most `reject_tries`
 //    rounds per iteration; lanes still without a direction sit out one trace instead of making 63
 //    lanes wait for the unluckiest one.
+//  * SKY TILES. A small double-precision kernel proves, per 8x8 tile, that no primary ray of the tile can hit a
+//    sphere in the literal arithmetic; the wave that fetches such a tile finishes it on the spot (draws + miss
+//    colour, lane = pixel) instead of tracing it.
 //  * The accumulation image is read once and written once per pixel and launch, in place.
 //
 // Two arithmetic modes (rt_types.h). RT_MATH_STRICT: phase 2, shading and accumulation restate
