@@ -167,7 +167,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // 6 waves per SIMD are resident (<= 80 VGPRs); the small-scene variants fit 7 (<= 72 VGPRs), which pays when a
   // rank has enough tiles to keep 28 waves per CU busy to the end (C3: -1.5 %; C2 with 5 tiles per wave: +4 %, so not there)
   uint32_t wpc = 24u;
-  if (!ctx->counting && a.n_spheres <= 128u && (uint64_t)my_tiles >= 16ull * 28ull * (uint64_t)ctx->compute_units) wpc = 28u;
+  if (!ctx->counting && a.n_spheres <= 64u /* RT_SMALL_MAX: the variants built for 7 waves */ && (uint64_t)my_tiles >= 16ull * 28ull * (uint64_t)ctx->compute_units) wpc = 28u;
   if (ctx->waves_per_cu > 0) wpc = (uint32_t)ctx->waves_per_cu;
   const uint64_t resident = (uint64_t)ctx->compute_units * wpc;
   // STAGED LAUNCH (batches only): a pixel is sequential, so with few tiles per wave the launch would end on

@@ -99,8 +99,8 @@ __device__ __forceinline__ float dot_fast(float ax, float ay, float az, float bx
 // and the generic code sits behind `if (ballot(rare))`, one scalar branch. A per-lane `if` would cost
 // five to seven scalar instructions of exec-mask bookkeeping per call, and scalar instructions take
 // issue slots like vector ones (profiles/r1_valu_ubench.txt, "fma+salu").
-#ifndef RT_CULL_MAX
-#define RT_CULL_MAX 128u  // largest scene (spheres) for which the strict kernel culls spheres behind the ray in phase 1
+#ifndef RT_SMALL_MAX
+#define RT_SMALL_MAX 64u  // largest scene (spheres) of the SMALL variants: sphere records in LDS, behind cull (strict), 7 waves per SIMD
 #endif
 #define RT_RARELY(cond) (__builtin_expect(__ballot(cond) != 0ull, 0))
 
@@ -263,8 +263,10 @@ __device__ __forceinline__ uint32_t combine_frame(float& acc0, float& acc1, floa
 // the parked states are 1 and 2 (one unsigned compare), everything runnable is >= ST_READY
 enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_FRAME_END = 2, ST_READY = 3, ST_NEED_DIR = 4, ST_NEW_RAY = 5, ST_PATH_DONE = 6, ST_GOT_DIR = 7 };
 
-// STRICT: arithmetic mode. COUNT: event counters for the roofline. CULL: phase 1 also drops spheres
-// behind the ray (strict, non-counting launches on small scenes; chosen by rt_launch_path_kernel).
+// STRICT: arithmetic mode. COUNT: event counters for the roofline. SMALL: scenes of at most RT_SMALL_MAX spheres
+// (non-counting launches; chosen by rt_launch_path_kernel) - the per-sphere records of phase 2 and of the shading are
+// staged in LDS (a gather from LDS returns in ~100 cycles, from L1/L2 in several hundred: C2 strict -5 %, C3 -1 %), and
+// strict launches also drop spheres behind the ray in phase 1 (CULL).
 // COLD KERNEL ARGUMENTS. Everything the per-pixel parts need (camera matrix, image geometry, buffers, frame
 // table) is read from the kernarg segment where it is used - behind a laundered pointer, so the compiler
 // cannot hoist the loads to the kernel entry and then keep ~40 scalar registers alive (and spilled into
@@ -276,13 +278,14 @@ __device__ __forceinline__ rt_kargs_cptr cold_args() {
   return p;
 }
 
-template <bool STRICT, bool COUNT, bool CULL>
+template <bool STRICT, bool COUNT, bool SMALL>
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 6  // keeps the production variants at <= 80 VGPRs = 6 waves per SIMD (measured: C3 strict -2.7 %)
 #endif
-// The small-scene variants (strict + cull; fast needs 70 VGPRs anyway) are held to 72 VGPRs = 7 waves per SIMD: big
+// The small-scene variants are held to 72 VGPRs = 7 waves per SIMD: big
 // images of small scenes gain 1-2 % from the seventh wave (profiles/r1e_ab_waves.log), the 1024-sphere scene loses 3 %.
-__global__ __launch_bounds__(64, (CULL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_path_kernel(const rt_kargs a) {
+__global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_path_kernel(const rt_kargs a) {
+  constexpr bool CULL = SMALL && STRICT;
   const uint32_t lane = threadIdx.x;
   const bool checker = (a.flags & RT_SHADE_CHECKER) != 0;
   const bool accum_f32 = (a.flags & RT_ACCUM_F32) != 0;
@@ -291,6 +294,16 @@ __global__ __launch_bounds__(64, (CULL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_pa
   const uint32_t n_spheres = a.n_spheres;
   const float spp_f = (float)a.spp;
   __shared__ f32x4 tile_lds[128];  // per wave: 64 pixel records {pixel_center, v<<16|u} {pixel_delta, seed x^y}
+  __shared__ f32x4 sph_lds[SMALL ? 3u * RT_SMALL_MAX : 1u];  // SMALL: sph_test | sph_shade | sph_col of the whole scene
+  if (SMALL) {
+    for (uint32_t i = lane; i < n_spheres; i += 64u) {
+      sph_lds[i] = a.sph_test[i];
+      sph_lds[RT_SMALL_MAX + i] = a.sph_shade[i];
+      sph_lds[2u * RT_SMALL_MAX + i] = a.sph_col[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 
   uint32_t c_T = 0, c_D = 0, c_H = 0, c_R = 0, c_M = 0, c_S = 0, c_Sm = 0, c_J = 0, c_Sd = 0, c_N = 0, c_P = 0, c_rand = 0;
   uint32_t c_wt = 0, c_wr = 0;  // wave-level iteration counts (diagnostics)
@@ -693,7 +706,7 @@ __global__ __launch_bounds__(64, (CULL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_pa
           const uint32_t lz = (uint32_t)__builtin_clz(cand);
           cand &= ~(0x80000000u >> lz);
           const uint32_t i = base + cnt_pad - 32u + lz;
-          const f32x4 s = a.sph_test[i];
+          const f32x4 s = SMALL ? sph_lds[i] : a.sph_test[i];
           const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
           if (STRICT) {
             // hit_sphere (wgsl:200-231), literal
@@ -745,8 +758,8 @@ __global__ __launch_bounds__(64, (CULL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_pa
         state = ST_PATH_DONE;
       } else {
         if (COUNT) { c_H++; c_S++; }
-        const f32x4 sg = a.sph_shade[hit];  // {cx, cy, cz, r}
-        const f32x4 sc = a.sph_col[hit];    // {material r, g, b, +-1/r}
+        const f32x4 sg = SMALL ? sph_lds[RT_SMALL_MAX + (uint32_t)hit] : a.sph_shade[hit];      // {cx, cy, cz, r}
+        const f32x4 sc = SMALL ? sph_lds[2u * RT_SMALL_MAX + (uint32_t)hit] : a.sph_col[hit];   // {material r, g, b, +-1/r}
         // hit record of the closest sphere (wgsl:225-227): point = ray_at(t), normal = (point - c) / r
         float px, py, pz, nx, ny, nz;
         if (STRICT) {
@@ -961,15 +974,17 @@ __global__ void rt_quantize_kernel(const f32x4* __restrict__ src, uint32_t* __re
 hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, hipStream_t stream) {
   if (n_waves == 0 || a.my_tiles == 0) return hipSuccess;
   const dim3 grid(n_waves), block(64);
-  // The behind cull saves exact tests (dear in strict mode, cheap in fast mode) for one more instruction
-  // per sphere test: used while the scene is small (measured: C3 20 spheres -3 %, C4 1024 spheres +2 %).
-  // Counting launches keep every candidate: the oracle's D counts their discriminants.
+  // SMALL variants while the scene fits their LDS arrays. The behind cull they carry in strict mode saves exact tests
+  // for one more instruction per sphere test (measured: 20 spheres -3 %, 1024 spheres +2 %). Counting launches keep
+  // every candidate: the oracle's D counts their discriminants.
+  const bool small = a.n_spheres <= RT_SMALL_MAX;
   if (strict) {
     if (count) hipLaunchKernelGGL((rt_path_kernel<true, true, false>), grid, block, 0, stream, a);
-    else if (a.n_spheres <= RT_CULL_MAX) hipLaunchKernelGGL((rt_path_kernel<true, false, true>), grid, block, 0, stream, a);
+    else if (small) hipLaunchKernelGGL((rt_path_kernel<true, false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rt_path_kernel<true, false, false>), grid, block, 0, stream, a);
   } else {
     if (count) hipLaunchKernelGGL((rt_path_kernel<false, true, false>), grid, block, 0, stream, a);
+    else if (small) hipLaunchKernelGGL((rt_path_kernel<false, false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rt_path_kernel<false, false, false>), grid, block, 0, stream, a);
   }
   return hipGetLastError();
