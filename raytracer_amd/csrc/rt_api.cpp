@@ -164,12 +164,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.reject_tries = a.n_spheres <= 8u ? (strict_math ? 3u : 2u) : (a.n_spheres <= 64u ? 3u : 64u);
   if (ctx->reject_tries > 0) a.reject_tries = (uint32_t)ctx->reject_tries;
   // Persistent launch: enough single-wave workgroups to fill every SIMD, never more than tiles.
-  // 6 waves per SIMD are resident (<= 80 VGPRs); the small-scene variants fit 7 (<= 72 VGPRs), which pays when a
-  // rank has enough tiles to keep 28 waves per CU busy to the end (C3: -1.5 %; C2 with 5 tiles per wave: +4 %, so not there)
-  uint32_t wpc = 24u;
-  if (!ctx->counting && a.n_spheres <= 64u /* RT_SMALL_MAX: the variants built for 7 waves */ && (uint64_t)my_tiles >= 16ull * 28ull * (uint64_t)ctx->compute_units) wpc = 28u;
-  if (ctx->waves_per_cu > 0) wpc = (uint32_t)ctx->waves_per_cu;
-  const uint64_t resident = (uint64_t)ctx->compute_units * wpc;
+  const uint64_t resident = (uint64_t)ctx->compute_units * 24u;  // 6 waves per SIMD (<= 80 VGPRs): the measure of the staging rule
   // STAGED LAUNCH (batches only): a pixel is sequential, so with few tiles per wave the launch would end on
   // the waves that drew the dearest pixels - for all n_frames of them. When a rank has fewer than
   // RT_STAGE_BELOW tiles per wave (and at least RT_STAGE_MIN_SPP samples per pixel), the unit of work becomes (tile, frame): the frames' colours go to a
@@ -196,7 +191,14 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
       a.n_units = my_tiles * n_frames;
     }
   }
-  const uint32_t n_waves = (uint32_t)(resident < a.n_units ? resident : a.n_units);
+  // Launch width: 6 waves per SIMD are resident (<= 80 VGPRs); the SMALL variants fit 7 (<= 72 VGPRs), which pays
+  // when there are enough units of work to keep 28 waves per CU busy to the end (C3 -1.5 %, batched C2 -4 %; one C2
+  // pass with 4.5 tiles per wave: +4 %, so not there)
+  uint32_t wpc = 24u;
+  if (!ctx->counting && a.n_spheres <= 64u /* RT_SMALL_MAX */ && (uint64_t)a.n_units >= 8ull * 28ull * (uint64_t)ctx->compute_units) wpc = 28u;
+  if (ctx->waves_per_cu > 0) wpc = (uint32_t)ctx->waves_per_cu;
+  const uint64_t launch_waves = (uint64_t)ctx->compute_units * wpc;
+  const uint32_t n_waves = (uint32_t)(launch_waves < a.n_units ? launch_waves : a.n_units);
   // host-side shape check before the launch: every tile index a block can form is < n_tiles or
   // rejected by the kernel's own guard; every pixel index is < width*height by construction of cov_*
   if (a.cov_w > a.width || a.cov_h > a.height) return fail(RT_ERR_INVALID, "covered area exceeds the image");
