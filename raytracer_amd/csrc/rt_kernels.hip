@@ -924,7 +924,12 @@ __global__ __launch_bounds__(256) void rt_sky_tiles_kernel(const rt_kargs a, uin
   const double rho = (3.5 * (n0 + n1) + 0.5 * (fabs(c0[0] - c1[0]) + fabs(c0[1] - c1[1]))) * (1.0 + 0x1p-20) + 0x1p-18 * mag;
   const double ndc = sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]);
   bool ok = a.p1_tame != 0u && rho < 0.25 * ndc && oo <= 0x1p39 && (ndc - rho) * (ndc - rho) >= 0x1p-19 && (ndc + rho) * (ndc + rho) <= 0x1p19;
-  if (ok) {  // also false for NaN / inf matrices
+  // The third column is multiplied by 0.0 (wgsl:86) and does not enter the bound, but a non-finite entry there makes
+  // every direction NaN - and a NaN root passes hit_sphere's range tests, i.e. such rays HIT: never a sky tile.
+  float colsum = 0.0f;
+  for (int i = 0; i < 16; ++i) colsum += a.p2w[i] * 0.0f;
+  ok = ok && colsum == 0.0f;
+  if (ok) {  // also false for NaN / inf in the columns used above
     const double sin_t = rho / ndc, cos_t = sqrt(1.0 - sin_t * sin_t);
     for (uint32_t i = 0; i < a.n_spheres; ++i) {
       const rt_f32x4 sp = a.sph_shade[i];
