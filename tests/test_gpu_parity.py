@@ -673,3 +673,19 @@ def test_deferred_passes_are_flushed_by_observers():
     one(3, 1, 2)
     assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
     rt.close()
+
+
+def test_sky_tiles_are_off_for_a_non_finite_camera(monkeypatch):
+    """A non-finite pixel_to_world entry - even in the column the shader multiplies by 0.0 - makes every ray NaN, and
+    NaN roots pass hit_sphere's range tests (wgsl:214-222): such rays hit. No tile may then be treated as sky."""
+    R = _rt()
+    W, H = 256, 160
+    sp, mt = scenes.default_scene(1)
+    cam = scenes.camera_raw(W, H, spp=1, frames=2, look=(0.0, 0.6, -1.0))
+    cam["pixel_to_world"][8] = np.inf
+    monkeypatch.setenv("RT_SKY_TILES", "1")
+    on = _render_state(R, W, H, O.ACCUM_F32, sp, mt, cam, 1, False)
+    assert on[3][0] == 0 and on[3][1] > 0
+    monkeypatch.setenv("RT_SKY_TILES", "0")
+    off = _render_state(R, W, H, O.ACCUM_F32, sp, mt, cam, 1, False)
+    assert np.array_equal(on[0], off[0]) and np.array_equal(on[1], off[1])
