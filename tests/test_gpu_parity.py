@@ -689,3 +689,24 @@ def test_sky_tiles_are_off_for_a_non_finite_camera(monkeypatch):
     monkeypatch.setenv("RT_SKY_TILES", "0")
     off = _render_state(R, W, H, O.ACCUM_F32, sp, mt, cam, 1, False)
     assert np.array_equal(on[0], off[0]) and np.array_equal(on[1], off[1])
+
+
+@pytest.mark.parametrize("knob,value", [("RT_REJECT_TRIES", "1"), ("RT_REJECT_TRIES", "5"), ("RT_BATCH_LANES", "1"), ("RT_BATCH_LANES", "9"),
+                                        ("RT_WAVES_PER_CU", "3"), ("RT_WAVES_PER_CU", "32"), ("RT_STAGED_FRAMES", "0"),
+                                        ("RT_TILE_ORDER", "0"), ("RT_DEFER_FRAMES", "3")])
+def test_launch_knobs_change_no_bit(knob, value, monkeypatch):
+    """Launch width, rejection rounds per iteration, parked lanes per service, staging, tile order and the size of a
+    deferred batch only move work between lanes and launches: each pixel consumes its own RNG stream in the
+    reference's order, so image and RNG states stay the oracle's."""
+    R = _rt()
+    W, H, spp, frames = 160, 96, 4, 5
+    sp, mt = scenes.random_bunch(20, 3, 3)
+    flags = O.ACCUM_F32 | O.SHADE_CHECKER
+    cam = scenes.camera_raw(W, H, spp=spp, frames=frames)
+    img = O.OracleImage(W, H, flags)
+    O.render(img, sp, mt, cam, 0, frames)
+    monkeypatch.setenv(knob, value)
+    rt = _run_gpu(R, W, H, flags, sp, mt, cam, frames)
+    assert np.array_equal(rt.read_rng_state(), img.rng)
+    assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
+    rt.close()
