@@ -70,6 +70,19 @@ int rt_compute(rt_ctx* ctx);
  * bit-identical to n_frames x (rt_set_time, rt_compute, current_frame += 1). Asynchronous. */
 int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames);
 
+/* rt_render_frames for callers that cannot allocate (no counterpart in the reference; for code under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc): the same n_frames redraws with the same results,
+ * bit for bit, but this call performs no hipMalloc / hipFree / hipHostMalloc / event creation on any path. The device
+ * scratch a launch needs beyond its inputs and outputs (tile queue head, frame table, sky-tile flags) lives in a
+ * 2.1 MB array in the library's device image, one copy per GPU, held until the process ends. Limits, rejected with
+ * RT_ERR_INVALID and a message: n_frames <= 256; at most 524 288 8x8 tiles in the context's partition (an 8K image has
+ * 518 400). RT_ERR_STATE while passes recorded by rt_compute are pending (call rt_sync first). Every call on a GPU
+ * shares that GPU's array and rewrites what it uses, so two calls that overlap on one GPU (two contexts on different
+ * streams) race; calls on one stream, or separated by rt_sync, do not. Not used here: staged (tile, frame) batches,
+ * the cost-ordered tile queue and per-launch timing events, all of which need buffers of their own - expect a few per
+ * cent less throughput than rt_render_frames on the same input. Asynchronous like rt_render_frames. */
+int rt_render_frames_static(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames);
+
 /* queue.submit + device wait (app.rs:111). */
 int rt_sync(rt_ctx* ctx);
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "rt_set_time": (C.c_int, [_VP, C.c_uint32]),
     "rt_compute": (C.c_int, [_VP]),
     "rt_render_frames": (C.c_int, [_VP, _VP, C.c_uint32]),
+    "rt_render_frames_static": (C.c_int, [_VP, _VP, C.c_uint32]),
     "rt_sync": (C.c_int, [_VP]),
     "rt_read_rgba8": (C.c_int, [_VP, _VP, C.c_size_t]),
     "rt_read_accum_f32": (C.c_int, [_VP, _VP, C.c_size_t]),

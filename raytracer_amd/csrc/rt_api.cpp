@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -29,6 +30,41 @@ int fail(int code, const std::string& msg) {
     if (e__ != hipSuccess)                                                                        \
       return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                \
   } while (0)
+
+// ---- scratch of rt_render_frames_static (include/rt_hip.h): the device memory a launch needs beyond its inputs and
+// outputs, in a file-scope array instead of hipMalloc'ed buffers. Layout (bytes):
+//   [0, 256)                     tile queue head of the persistent kernel (one u32, zeroed before every launch)
+//   [256, 256 + 8 * MAX_FRAMES)  frame table {seed_t, bits of cw} of a batched launch
+//   [.., .. + 4 * MAX_TILES)     sky-tile flags of the calling context's partition (rewritten by every call)
+// Every GPU the library runs on holds its own copy (2.1 MB) until the process ends. `rt_static_scratch` is a host-side
+// stand-in, NOT a device address: host code uses the per-device pointer hipGetSymbolAddress returned (scratch_ptr()).
+constexpr uint32_t RT_STATIC_MAX_FRAMES = 256;
+constexpr uint32_t RT_STATIC_MAX_TILES = 1u << 19;  // 8x8 tiles of one context's partition (7680x4320 has 518 400)
+constexpr size_t RT_STATIC_OFF_TABLE = 256;
+constexpr size_t RT_STATIC_OFF_SKY = RT_STATIC_OFF_TABLE + 8u * RT_STATIC_MAX_FRAMES;
+constexpr size_t RT_STATIC_BYTES = RT_STATIC_OFF_SKY + 4u * (size_t)RT_STATIC_MAX_TILES;
+}  // namespace
+
+static __device__ __align__(256) unsigned char rt_static_scratch[RT_STATIC_BYTES];
+
+namespace {
+
+constexpr int RT_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[RT_MAX_DEVICES] = {};
+
+// Device address of this device's copy of the scratch array; resolved once per device, with that device current
+// (rt_create calls this right after hipSetDevice).
+int resolve_scratch(int device) {
+  if (device < 0 || device >= RT_MAX_DEVICES) return fail(RT_ERR_INVALID, "device index beyond RT_MAX_DEVICES");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[device]) return RT_OK;
+  void* p = nullptr;
+  RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(rt_static_scratch)));
+  if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress(rt_static_scratch) returned null");
+  g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+  return RT_OK;
+}
 
 }  // namespace
 
@@ -76,6 +112,7 @@ struct rt_ctx {
   size_t time_cap = 0;
   hipEvent_t time_copied = nullptr;
   bool time_pending = false;
+  uint2* static_time_host = nullptr;  // pinned, RT_STATIC_MAX_FRAMES entries, allocated by rt_create for rt_render_frames_static
   // RGBA8 view of a float image
   void* quant = nullptr;
   // staged launches: frame colours of a batch (n_frames x width x height float4)
@@ -122,7 +159,11 @@ float frame_cw(uint32_t frame) {
   return f / n;
 }
 
-int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_bits0, const uint2* time_table_dev) {
+// `scratch` != null: the launch of rt_render_frames_static - queue head and sky flags live in the static scratch array
+// (time_table_dev already points into it), and nothing here may allocate: no staging buffer, no cost-ordered queue
+// (its two arrays), no timing events.
+int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_bits0, const uint2* time_table_dev,
+           unsigned char* scratch = nullptr) {
   rt_kargs a{};
   std::memcpy(a.p2w, ctx->camera.pixel_to_world, sizeof a.p2w);
   a.pos[0] = ctx->camera.pos[0];
@@ -153,11 +194,14 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.accum = ctx->accum;
   a.rng_out = ctx->rng_capture ? ctx->rng : nullptr;
   a.counters = ctx->counters;
-  a.queue = ctx->queue;
+  a.queue = scratch ? reinterpret_cast<uint32_t*>(scratch) : ctx->queue;
   if (a.n_tiles == 0) return RT_OK;
   const uint32_t my_tiles = a.n_tiles > a.rank ? (a.n_tiles - a.rank + a.world - 1u) / a.world : 0u;
   a.my_tiles = my_tiles;
   if (my_tiles == 0) return RT_OK;
+  if (scratch && my_tiles > RT_STATIC_MAX_TILES)
+    return fail(RT_ERR_INVALID, "rt_render_frames_static: " + std::to_string(my_tiles) + " tiles in this context's partition, the static scratch holds " +
+                                    std::to_string(RT_STATIC_MAX_TILES) + " (use rt_render_frames)");
   // Rejection rounds per iteration: a lane that sits out pays one trace, so allow more rounds
   // the more a trace costs ("bounded rejection").
   const bool strict_math = (ctx->flags & RT_MATH_FAST) == 0;
@@ -171,7 +215,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // staging buffer and a second kernel folds them into the image in order (same arithmetic, bit-identical).
   a.n_units = my_tiles;
   const size_t stage_bytes = (size_t)n_frames * ctx->width * ctx->height * sizeof(rt_f32x4);
-  if (ctx->use_staging && n_frames > 1 && time_table_dev && a.spp >= RT_STAGE_MIN_SPP && (uint64_t)my_tiles < RT_STAGE_BELOW * resident &&
+  if (!scratch && ctx->use_staging && n_frames > 1 && time_table_dev && a.spp >= RT_STAGE_MIN_SPP && (uint64_t)my_tiles < RT_STAGE_BELOW * resident &&
       stage_bytes <= RT_STAGE_MAX_BYTES && (uint64_t)my_tiles * n_frames < 0xffffffffull / 64u) {
     if (ctx->staging_bytes < stage_bytes) {
       RT_HIP(hipStreamSynchronize(ctx->stream));
@@ -203,7 +247,8 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // rejected by the kernel's own guard; every pixel index is < width*height by construction of cov_*
   if (a.cov_w > a.width || a.cov_h > a.height) return fail(RT_ERR_INVALID, "covered area exceeds the image");
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (ctx->timing) {  // the events bracket the path kernel alone (what rocprofv3 reports as its duration)
+  const bool timing = ctx->timing && !scratch;
+  if (timing) {  // the events bracket the path kernel alone (what rocprofv3 reports as its duration)
     if (ctx->events_used == ctx->events.size()) {
       RT_HIP(hipEventCreate(&e0));
       RT_HIP(hipEventCreate(&e1));
@@ -217,7 +262,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // Cost-ordered queue (only worth it when there are more tiles than waves): hand tiles out dearest
   // first, by the cost measured in an earlier launch of the same partition, scene and camera. The
   // measurement (one atomic per pixel) runs in the first launch and every RT_ORDER_REFRESH-th after.
-  const bool ordering = ctx->use_order && my_tiles > n_waves;
+  const bool ordering = !scratch && ctx->use_order && my_tiles > n_waves;
   bool measure = false;
   const uint32_t key = a.rank * 65536u + a.world;
   if (ordering) {
@@ -242,7 +287,13 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   }
   // Sky tiles: recomputed (inside the timed region) whenever the scene, the camera or the partition changed.
   // Counting launches trace every tile, so their event counters stay the oracle's.
-  if (ctx->use_sky && !ctx->counting) {
+  if (scratch && ctx->use_sky && !ctx->counting) {
+    // the scratch is shared by every context on this GPU and keeps the last call's contents: the flags of this
+    // context's my_tiles tiles are rewritten by every call (15 us at 4K)
+    uint32_t* flags = reinterpret_cast<uint32_t*>(scratch + RT_STATIC_OFF_SKY);
+    RT_HIP(rt_launch_sky_tiles(a, flags, ctx->stream));
+    a.sky_flags = flags;
+  } else if (ctx->use_sky && !ctx->counting) {
     if (ctx->sky_tiles_cap != my_tiles) {
       RT_HIP(hipStreamSynchronize(ctx->stream));
       (void)hipFree(ctx->sky_flags);
@@ -260,10 +311,10 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     }
     a.sky_flags = ctx->sky_flags;
   }
-  RT_HIP(hipMemsetAsync(ctx->queue, 0, sizeof(uint32_t), ctx->stream));
-  if (ctx->timing) RT_HIP(hipEventRecord(e0, ctx->stream));
+  RT_HIP(hipMemsetAsync(a.queue, 0, sizeof(uint32_t), ctx->stream));
+  if (timing) RT_HIP(hipEventRecord(e0, ctx->stream));
   RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, ctx->stream));
-  if (ctx->timing) RT_HIP(hipEventRecord(e1, ctx->stream));
+  if (timing) RT_HIP(hipEventRecord(e1, ctx->stream));
   if (a.staging) RT_HIP(rt_launch_combine_frames(a, ctx->stream));
   if (measure) {
     RT_HIP(rt_launch_tile_order(ctx->tile_cost, ctx->tile_order, my_tiles, ctx->stream));
@@ -306,6 +357,28 @@ int launch_batch(rt_ctx* ctx, const uint32_t* frames, const uint32_t* time_bits,
   return launch(ctx, frames[0], n, time_bits[0], ctx->time_dev);
 }
 
+// launch_batch for rt_render_frames_static: the frame table goes through the context's pinned buffer (allocated by
+// rt_create) into the static scratch; no allocation on any path.
+int launch_batch_static(rt_ctx* ctx, const uint32_t* frames, const uint32_t* time_bits, uint32_t n, unsigned char* scratch) {
+  if (n == 0) return RT_OK;
+  if (n == 1) return launch(ctx, frames[0], 1, time_bits[0], nullptr, scratch);
+  if (ctx->time_pending) {  // a pinned table may still be in flight from the previous batch
+    RT_HIP(hipEventSynchronize(ctx->time_copied));
+    ctx->time_pending = false;
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    const float cw = frame_cw(frames[i]);
+    uint32_t cw_bits;
+    std::memcpy(&cw_bits, &cw, 4);
+    ctx->static_time_host[i] = make_uint2(time_bits[i] * 87189u + 189273u, cw_bits);
+  }
+  uint2* table = reinterpret_cast<uint2*>(scratch + RT_STATIC_OFF_TABLE);
+  RT_HIP(hipMemcpyAsync(table, ctx->static_time_host, n * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+  RT_HIP(hipEventRecord(ctx->time_copied, ctx->stream));
+  ctx->time_pending = true;
+  return launch(ctx, frames[0], n, time_bits[0], table, scratch);
+}
+
 // Launches the passes rt_compute has recorded. Called by every entry point that observes the image, the counters or
 // the timing, or that changes something a recorded pass depends on; an error of the launch is that call's error.
 int flush_pending(rt_ctx* ctx) {
@@ -345,6 +418,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(RT_ERR_NO_DEVICE, std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
   RT_HIP(hipSetDevice(device));
+  if (int rc = resolve_scratch(device)) return rc;  // once per device, with that device current
   rt_ctx* c = new (std::nothrow) rt_ctx();
   if (!c) return fail(RT_ERR_INVALID, "out of host memory");
   c->device = device;
@@ -367,6 +441,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e6 = std::getenv("RT_SKY_TILES")) c->use_sky = std::atoi(e6);
   if (const char* e7 = std::getenv("RT_DEFER_FRAMES")) c->defer_max = std::atoi(e7);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->static_time_host, RT_STATIC_MAX_FRAMES * sizeof(uint2), hipHostMallocDefault);
   if (e == hipSuccess) {
     c->stream = c->own_stream;
     e = hipMemsetAsync(c->accum, 0, c->accum_bytes, c->stream);
@@ -409,6 +484,7 @@ void rt_destroy(rt_ctx* c) {
   (void)hipFree(c->quant);
   (void)hipFree(c->staging);
   if (c->time_host) (void)hipHostFree(c->time_host);
+  if (c->static_time_host) (void)hipHostFree(c->static_time_host);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -537,6 +613,31 @@ int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames) 
   }
   if (rc != RT_OK) return rc;
   ctx->camera.current_frame = cur + n_frames;  // Camera::increase_frame once per redraw (camera.rs:253)
+  ctx->time_bits = time_bits[n_frames - 1];
+  ctx->have_time = true;
+  return RT_OK;
+}
+
+int rt_render_frames_static(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames) {
+  if (int rc = check(ctx)) return rc;
+  if (!ctx->have_scene || !ctx->have_camera) return fail(RT_ERR_STATE, "rt_render_frames_static before rt_set_scene / rt_set_camera");
+  if (!time_bits || n_frames == 0) return fail(RT_ERR_INVALID, "empty time table");
+  if (n_frames > RT_STATIC_MAX_FRAMES)
+    return fail(RT_ERR_INVALID, "rt_render_frames_static: " + std::to_string(n_frames) + " frames, the static scratch holds a table of " +
+                                    std::to_string(RT_STATIC_MAX_FRAMES) + " (split the call or use rt_render_frames)");
+  // recorded passes would be launched by the allocating path: the caller has to have them run first
+  if (!ctx->pend_frames.empty())
+    return fail(RT_ERR_STATE, "rt_render_frames_static: passes recorded by rt_compute are pending; call rt_sync first");
+  unsigned char* scratch = g_scratch_ptr[ctx->device];  // this device's copy (resolve_scratch in rt_create)
+  if (!scratch) return fail(RT_ERR_STATE, "rt_render_frames_static: scratch address of this device was never resolved");
+  const uint32_t cur = ctx->camera.current_frame, total = ctx->camera.frames_to_render;
+  const uint32_t live = cur < total ? (n_frames < total - cur ? n_frames : total - cur) : 0u;  // rest are no-ops (wgsl:76)
+  if (live > 0) {
+    uint32_t frames[RT_STATIC_MAX_FRAMES];
+    for (uint32_t i = 0; i < live; ++i) frames[i] = cur + i;
+    if (int rc = launch_batch_static(ctx, frames, time_bits, live, scratch)) return rc;
+  }
+  ctx->camera.current_frame = cur + n_frames;
   ctx->time_bits = time_bits[n_frames - 1];
   ctx->have_time = true;
   return RT_OK;

@@ -99,6 +99,11 @@ class Raytracer:
         t = np.ascontiguousarray(time_bits, dtype=np.uint32)
         check(self._lib.rt_render_frames(self._h, _ptr(t), t.shape[0]))
 
+    def render_frames_static(self, time_bits):
+        """rt_render_frames without any allocation (static device scratch; include/rt_hip.h has the limits)."""
+        t = np.ascontiguousarray(time_bits, dtype=np.uint32)
+        check(self._lib.rt_render_frames_static(self._h, _ptr(t), t.shape[0]))
+
     def sync(self):
         check(self._lib.rt_sync(self._h))
 

@@ -1,0 +1,85 @@
+"""rt_render_frames_static — the entry point that allocates nothing (include/rt_hip.h) — against rt_render_frames.
+
+Called through the C ABI on two inputs in a row, the second smaller than the first (fewer tiles, fewer frames, fewer
+spheres), so that the second call runs over the first call's leftovers in the per-GPU static scratch. Bar: bit-exact
+(RGBA8 / float image and every pixel's final RNG state), as for every strict-mode result. Collected last on purpose:
+the round-end run uses `pytest -x`.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(R, static, W, H, flags, spheres, mats, spp, frames, calls):
+    """`calls` = frame counts of consecutive render calls on one context. Returns (rgba8, f32 or None, rng)."""
+    rt = R.Raytracer(W, H, flags)
+    rt.set_scene(spheres, mats)
+    rt.enable_rng_capture(True)
+    rt.set_camera(scenes.camera_raw(W, H, spp=spp, frames=frames))
+    tb = O.time_bits_table(frames)
+    at = 0
+    for n in calls:
+        (rt.render_frames_static if static else rt.render_frames)(tb[at:at + n])
+        at += n
+    rt.sync()
+    out = (rt.read_rgba8(), rt.read_accum_f32() if flags & R.RT_ACCUM_F32 else None, rt.read_rng_state())
+    rt.close()
+    return out
+
+
+def _same(a, b):
+    assert np.array_equal(a[0], b[0]), "RGBA8 image differs"
+    if a[1] is not None:
+        assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), "float image differs"
+    assert np.array_equal(a[2], b[2]), "final RNG states differ"
+
+
+def test_static_entry_point_matches_render_frames_twice_in_a_row_second_call_smaller():
+    import raytracer_amd as R
+
+    big = dict(W=272, H=208, flags=R.RT_ACCUM_F32 | R.RT_SHADE_CHECKER, spp=4, frames=5)
+    small = dict(W=96, H=64, flags=R.RT_ACCUM_RGBA8, spp=2, frames=3)
+    s_big, s_small = scenes.random_bunch(20, 3, 3), scenes.default_scene(1)
+    # first call: 884 tiles, 5 frames, 20 spheres; second: 96 tiles, 3 frames, 4 spheres - over the first call's leftovers
+    got_big = _render(R, True, spheres=s_big[0], mats=s_big[1], calls=[5], **big)
+    got_small = _render(R, True, spheres=s_small[0], mats=s_small[1], calls=[3], **small)
+    _same(got_big, _render(R, False, spheres=s_big[0], mats=s_big[1], calls=[5], **big))
+    _same(got_small, _render(R, False, spheres=s_small[0], mats=s_small[1], calls=[3], **small))
+    # and against the oracle itself
+    img = O.OracleImage(small["W"], small["H"], 0)
+    O.render(img, s_small[0], s_small[1], scenes.camera_raw(small["W"], small["H"], spp=small["spp"], frames=small["frames"]), 0, small["frames"])
+    assert np.array_equal(got_small[0], img.rgba8) and np.array_equal(got_small[2], img.rng)
+
+
+def test_static_entry_point_split_calls_on_one_context_and_past_the_end():
+    import raytracer_amd as R
+
+    sp, mt = scenes.default_scene(1)
+    kw = dict(W=80, H=48, flags=R.RT_ACCUM_RGBA8, spheres=sp, mats=mt, spp=3, frames=4)
+    # 2 + 1 + 3 frames on one context: single-frame launches take the kernarg path, the last call runs past frames_to_render
+    _same(_render(R, True, calls=[2, 1, 3], **{**kw, "frames": 4}), _render(R, False, calls=[2, 1, 3], **{**kw, "frames": 4}))
+
+
+def test_static_entry_point_rejects_what_it_cannot_hold():
+    import raytracer_amd as R
+
+    sp, mt = scenes.default_scene(1)
+    rt = R.Raytracer(64, 48, R.RT_ACCUM_RGBA8)
+    rt.set_scene(sp, mt)
+    rt.set_camera(scenes.camera_raw(64, 48, spp=1, frames=1000))
+    with pytest.raises(R.RtError) as e:
+        rt.render_frames_static(O.time_bits_table(257))
+    assert e.value.code == R._abi.RT_ERR_INVALID and "256" in str(e.value)
+    rt.set_time(int(O.time_bits_table(1)[0]))
+    rt.compute()  # recorded, not launched
+    with pytest.raises(R.RtError) as e:
+        rt.render_frames_static(O.time_bits_table(2))
+    assert e.value.code == R._abi.RT_ERR_STATE and "rt_sync" in str(e.value)
+    rt.sync()
+    rt.render_frames_static(O.time_bits_table(2))  # fine now
+    rt.sync()
+    rt.close()
