@@ -59,8 +59,11 @@ int rt_set_time(rt_ctx* ctx, uint32_t time_bits);
  * 8 passes, bit-identical to one launch per pass - when 8 wait or at the next call that observes the image, the
  * counters or the timing (rt_sync, rt_read_*, rt_get_counters, rt_timing_get, ...) or that changes what a recorded
  * pass depends on (scene, camera other than current_frame, partition, stream, bound image, rt_clear, rt_write_image);
- * a launch failure is reported by that call. RT_DEFER_FRAMES=1 in the environment (read by rt_create) launches every
- * pass at once. Passes run under rt_enable_counters launch at once, one by one. */
+ * a launch failure of a recorded pass is reported by THAT call (rt_flush / rt_sync are the calls to check when the
+ * status matters; rt_destroy runs pending passes and drops their status). RT_DEFER_FRAMES=1 in the environment (read
+ * by rt_create) launches every pass at once. Passes run under rt_enable_counters, and passes of a context that runs
+ * on a caller's stream (rt_set_stream), launch at once, one by one: there rt_compute enqueues the kernel before it
+ * returns. */
 int rt_compute(rt_ctx* ctx);
 
 /* Batched form of the App::update/App::render loop (app.rs:93-116) for `n_frames` redraws in ONE
@@ -82,6 +85,13 @@ int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames);
  * the cost-ordered tile queue and per-launch timing events, all of which need buffers of their own - expect a few per
  * cent less throughput than rt_render_frames on the same input. Asynchronous like rt_render_frames. */
 int rt_render_frames_static(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames);
+
+/* queue.submit without the wait (app.rs:111): launches the passes rt_compute has recorded and returns; a launch
+ * failure of a recorded pass is reported here (or by whichever observing call comes first, see rt_compute). Does not
+ * block, except that the first launch of a scene / image size may allocate its internal buffers, which synchronises
+ * the stream once. Stream-ordered callers that keep the context's own stream call this before they record an event or
+ * read the bound image from another stream. */
+int rt_flush(rt_ctx* ctx);
 
 /* queue.submit + device wait (app.rs:111). */
 int rt_sync(rt_ctx* ctx);
@@ -124,8 +134,14 @@ int rt_sky_tile_stats(rt_ctx* ctx, uint32_t* sky_tiles, uint32_t* tiles);
 
 /* Plumbing for callers that own device memory / streams (torch.distributed, HIP graphs):
  * rt_accum_device_ptr: device address and byte size of the accumulation image (RGBA8: W*H*4,
- *   F32: W*H*16), valid until rt_destroy.
- * rt_set_stream: run on the caller's hipStream_t (NULL = the context's own stream). */
+ *   F32: W*H*16), valid until rt_destroy. Launches recorded passes first (like rt_flush), so work the caller
+ *   enqueues AFTER this call on the context's stream - or after rt_sync on any stream - sees the finished image.
+ * rt_set_stream: run on the caller's hipStream_t (NULL = the context's own stream). While a caller's stream is set,
+ *   rt_compute launches at once instead of recording (no deferral), so stream order is what the caller sees.
+ *   Under hipStreamBeginCapture use rt_render_frames_static after one warm-up call: it never allocates or
+ *   synchronises; the other launch paths may do both the first time a buffer is needed.
+ * Rule for a bound image (rt_bind_accum) on the context's OWN stream: the caller's streams are not ordered against
+ *   it; call rt_sync (or rt_flush + an event of your own) before another stream reads the image. */
 int rt_accum_device_ptr(rt_ctx* ctx, void** dptr, size_t* bytes);
 /* rt_bind_accum: use caller-owned device memory (e.g. a torch tensor handed to RCCL) as the
  *   accumulation image from now on; `bytes` must equal the image size and the memory must stay

@@ -57,6 +57,15 @@ rt_ctx* rth_app_ctx(rth_app* app);            /* borrow the Raytracer's context 
 uint32_t rth_app_current_frame(rth_app* app);
 uint32_t rth_app_time_bits(rth_app* app);
 
+/* The App's camera under the interactive controls (App::on_event -> Camera::key_press / zoom / look_at_pixel,
+ * src/app.rs:50-91, src/resources/camera.rs:133-206) without winit: same key names and rules as rth_camera_*; each
+ * call ends with scene_was_updated (camera.rs:283-288): current_frame = 0 and the new CameraRaw is uploaded.
+ * rth_app_camera_get returns the 160 bytes the next pass will use. */
+int rth_app_camera_key(rth_app* app, const char* key);
+int rth_app_camera_zoom(rth_app* app, float val);
+int rth_app_camera_look_at_pixel(rth_app* app, float off_x, float off_y);
+int rth_app_camera_get(rth_app* app, rt_camera_raw* out, float* fov);
+
 /* Checkpoint / resume. No counterpart in the reference: its accumulation lives in two wgpu
  * textures and a render always restarts from frame 0 (src/resources/camera.rs:274-277). The file holds a
  * 128-byte header (image size, flags, frame counter, time bits, camera, a hash of the scene) and the

@@ -53,6 +53,7 @@ SIGNATURES = {
     "rt_compute": (C.c_int, [_VP]),
     "rt_render_frames": (C.c_int, [_VP, _VP, C.c_uint32]),
     "rt_render_frames_static": (C.c_int, [_VP, _VP, C.c_uint32]),
+    "rt_flush": (C.c_int, [_VP]),
     "rt_sync": (C.c_int, [_VP]),
     "rt_read_rgba8": (C.c_int, [_VP, _VP, C.c_size_t]),
     "rt_read_accum_f32": (C.c_int, [_VP, _VP, C.c_size_t]),

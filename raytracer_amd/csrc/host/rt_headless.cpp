@@ -59,6 +59,9 @@ int main(int argc, char** argv) {
     app.camera.samples_per_pixel = spp;
     app.camera.frames_to_render = frames;
     app.camera.reset_render();
+    // scene_was_updated (camera.rs:283-288): the constructor uploaded Camera::new's defaults (spp 1, 8 frames);
+    // App::render computes BEFORE its own camera upload, so frame 0 of --per-frame needs this one
+    app.ray_tracer.write_camera(app.camera.to_raw());
     if (!resume.empty()) {
       app.load_checkpoint(resume);
       std::printf("resumed %s at frame %u of %u\n", resume.c_str(), app.camera.current_frame, app.camera.frames_to_render);

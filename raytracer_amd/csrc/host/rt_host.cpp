@@ -514,17 +514,23 @@ struct rth_camera {
 
 rth_camera* rth_camera_create(uint32_t width, uint32_t height) { return (width && height) ? new rth_camera{rt::Camera(width, height)} : nullptr; }
 void rth_camera_destroy(rth_camera* c) { delete c; }
-int rth_camera_key(rth_camera* c, const char* key) {
-  if (!c || !key) { g_herr = "rth_camera_key: null argument"; return RT_ERR_INVALID; }
+static bool parse_key(const char* key, rt::Camera::Key* out) {
   static const struct { const char* name; rt::Camera::Key k; } table[] = {
       {"K", rt::Camera::Key::K}, {"J", rt::Camera::Key::J}, {"I", rt::Camera::Key::I}, {"U", rt::Camera::Key::U},
       {"ArrowUp", rt::Camera::Key::ArrowUp}, {"ArrowDown", rt::Camera::Key::ArrowDown}, {"Backspace", rt::Camera::Key::Backspace},
       {"W", rt::Camera::Key::W}, {"S", rt::Camera::Key::S}, {"D", rt::Camera::Key::D}, {"A", rt::Camera::Key::A},
       {"Space", rt::Camera::Key::Space}, {"ShiftLeft", rt::Camera::Key::ShiftLeft}};
   for (const auto& e : table)
-    if (std::strcmp(e.name, key) == 0) { c->cam.key_press(e.k); return RT_OK; }
+    if (std::strcmp(e.name, key) == 0) { *out = e.k; return true; }
   g_herr = std::string("unknown key ") + key;
-  return RT_ERR_INVALID;
+  return false;
+}
+int rth_camera_key(rth_camera* c, const char* key) {
+  if (!c || !key) { g_herr = "rth_camera_key: null argument"; return RT_ERR_INVALID; }
+  rt::Camera::Key k;
+  if (!parse_key(key, &k)) return RT_ERR_INVALID;
+  c->cam.key_press(k);
+  return RT_OK;
 }
 int rth_camera_zoom(rth_camera* c, float val) { if (!c) return RT_ERR_INVALID; c->cam.zoom(val); c->cam.reset_render(); return RT_OK; }
 int rth_camera_look_at_pixel(rth_camera* c, float off_x, float off_y) {
@@ -563,6 +569,9 @@ int rth_app_create(rth_app** out, int device, uint32_t width, uint32_t height, u
   } catch (const rt::Error& e) {
     g_herr = e.what;
     return e.code;
+  } catch (...) {  // nothing may unwind across the C ABI
+    g_herr = "host exception (out of memory?)";
+    return RT_ERR_INVALID;
   }
 }
 
@@ -576,6 +585,9 @@ static int guarded(rth_app* a, void (*fn)(rt::App&, uint32_t), uint32_t n) {
   } catch (const rt::Error& e) {
     g_herr = e.what;
     return e.code;
+  } catch (...) {  // nothing may unwind across the C ABI
+    g_herr = "host exception (out of memory?)";
+    return RT_ERR_INVALID;
   }
 }
 
@@ -585,14 +597,46 @@ int rth_app_redraw(rth_app* a, uint32_t n) {  // n x (App::update, App::render),
 int rth_app_run(rth_app* a, uint32_t n) {  // same redraws, batched into one launch
   return guarded(a, [](rt::App& app, uint32_t k) { app.run(k); }, n);
 }
+// App::on_event's camera half (app.rs:50-91 -> camera.rs:133-206) without winit: the control acts on the App's own
+// camera, then scene_was_updated (camera.rs:283-288): reset_render + upload of the new CameraRaw.
+static int app_camera_changed(rth_app* a) {
+  try {
+    a->app.camera.reset_render();
+    a->app.ray_tracer.write_camera(a->app.camera.to_raw());
+    return RT_OK;
+  } catch (const rt::Error& e) { g_herr = e.what; return e.code; } catch (...) { g_herr = "host exception (out of memory?)"; return RT_ERR_INVALID; }
+}
+int rth_app_camera_key(rth_app* a, const char* key) {
+  if (!a || !key) { g_herr = "rth_app_camera_key: null argument"; return RT_ERR_INVALID; }
+  rt::Camera::Key k;
+  if (!parse_key(key, &k)) return RT_ERR_INVALID;
+  a->app.camera.key_press(k);
+  return app_camera_changed(a);
+}
+int rth_app_camera_zoom(rth_app* a, float val) {
+  if (!a) { g_herr = "null app"; return RT_ERR_INVALID; }
+  a->app.camera.zoom(val);
+  return app_camera_changed(a);
+}
+int rth_app_camera_look_at_pixel(rth_app* a, float off_x, float off_y) {
+  if (!a) { g_herr = "null app"; return RT_ERR_INVALID; }
+  a->app.camera.look_at_pixel_from_center(off_x, off_y);
+  return app_camera_changed(a);
+}
+int rth_app_camera_get(rth_app* a, rt_camera_raw* out, float* fov) {
+  if (!a || !out) { g_herr = "rth_app_camera_get: null argument"; return RT_ERR_INVALID; }
+  *out = a->app.camera.to_raw();
+  if (fov) *fov = a->app.camera.fov;
+  return RT_OK;
+}
 int rth_app_save_checkpoint(rth_app* a, const char* path) {
   if (!a || !path) { g_herr = "rth_app_save_checkpoint: null argument"; return RT_ERR_INVALID; }
-  try { a->app.save_checkpoint(path); } catch (const rt::Error& e) { g_herr = e.what; return e.code; }
+  try { a->app.save_checkpoint(path); } catch (const rt::Error& e) { g_herr = e.what; return e.code; } catch (...) { g_herr = "host exception (out of memory?)"; return RT_ERR_INVALID; }
   return RT_OK;
 }
 int rth_app_load_checkpoint(rth_app* a, const char* path) {
   if (!a || !path) { g_herr = "rth_app_load_checkpoint: null argument"; return RT_ERR_INVALID; }
-  try { a->app.load_checkpoint(path); } catch (const rt::Error& e) { g_herr = e.what; return e.code; }
+  try { a->app.load_checkpoint(path); } catch (const rt::Error& e) { g_herr = e.what; return e.code; } catch (...) { g_herr = "host exception (out of memory?)"; return RT_ERR_INVALID; }
   return RT_OK;
 }
 int rth_checkpoint_info(const char* path, uint32_t out9[9], uint64_t* scene_hash, uint64_t* image_bytes) {
@@ -603,7 +647,7 @@ int rth_checkpoint_info(const char* path, uint32_t out9[9], uint64_t* scene_hash
     std::memcpy(out9, v, sizeof v);
     if (scene_hash) *scene_hash = i.scene_hash;
     if (image_bytes) *image_bytes = i.image_bytes;
-  } catch (const rt::Error& e) { g_herr = e.what; return e.code; }
+  } catch (const rt::Error& e) { g_herr = e.what; return e.code; } catch (...) { g_herr = "host exception (out of memory?)"; return RT_ERR_INVALID; }
   return RT_OK;
 }
 rt_ctx* rth_app_ctx(rth_app* a) { return a ? a->app.ray_tracer.ctx() : nullptr; }

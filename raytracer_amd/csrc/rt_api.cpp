@@ -255,8 +255,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
       ctx->events.emplace_back(e0, e1);
     }
     e0 = ctx->events[ctx->events_used].first;
-    e1 = ctx->events[ctx->events_used].second;
-    ctx->events_used++;
+    e1 = ctx->events[ctx->events_used].second;  // events_used is bumped once both are recorded (below)
   }
   const bool strict = (ctx->flags & RT_MATH_FAST) == 0;
   // Cost-ordered queue (only worth it when there are more tiles than waves): hand tiles out dearest
@@ -285,7 +284,10 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     }
     a.tile_order = ctx->have_order ? ctx->tile_order : nullptr;
   }
-  // Sky tiles: recomputed (inside the timed region) whenever the scene, the camera or the partition changed.
+  // Sky tiles: recomputed whenever the scene, the camera or the partition changed - inside the caller's wall clock,
+  // outside the hipEvents below, which bracket the path kernel alone (as rocprofv3 reports it); rt_sky_tiles_kernel
+  // (15 us at 4K, once per scene/camera) and rt_combine_frames_kernel (0.25 ms per 8-pass 4K batch, 0.3 % of the path
+  // kernel) are lines of their own in the rocprofv3 summaries under profiles/.
   // Counting launches trace every tile, so their event counters stay the oracle's.
   if (scratch && ctx->use_sky && !ctx->counting) {
     // the scratch is shared by every context on this GPU and keeps the last call's contents: the flags of this
@@ -314,7 +316,10 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   RT_HIP(hipMemsetAsync(a.queue, 0, sizeof(uint32_t), ctx->stream));
   if (timing) RT_HIP(hipEventRecord(e0, ctx->stream));
   RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, ctx->stream));
-  if (timing) RT_HIP(hipEventRecord(e1, ctx->stream));
+  if (timing) {
+    RT_HIP(hipEventRecord(e1, ctx->stream));
+    ctx->events_used++;
+  }
   if (a.staging) RT_HIP(rt_launch_combine_frames(a, ctx->stream));
   if (measure) {
     RT_HIP(rt_launch_tile_order(ctx->tile_cost, ctx->tile_order, my_tiles, ctx->stream));
@@ -589,7 +594,9 @@ int rt_compute(rt_ctx* ctx) {
   // Like Raytracer::compute, which only records the dispatch (raytracing.rs:178-200; app.rs:111 submits): the pass is
   // recorded, and up to defer_max recorded passes run as one batched launch (staged (tile, frame) units where that
   // pays) - bit-identical to launching them one by one, without each launch's tail. Counting launches stay single.
-  if (ctx->defer_max > 1 && !ctx->counting) {
+  // On a caller's stream (rt_set_stream) every pass is enqueued at once: such callers order their own work after ours
+  // on that stream (RCCL on the same stream, graph capture) and must find the kernel there.
+  if (ctx->defer_max > 1 && !ctx->counting && ctx->stream == ctx->own_stream) {
     ctx->pend_frames.push_back(ctx->camera.current_frame);
     ctx->pend_time.push_back(ctx->time_bits);
     if ((int)ctx->pend_frames.size() >= ctx->defer_max) RT_FLUSH(ctx);
@@ -640,6 +647,12 @@ int rt_render_frames_static(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_f
   ctx->camera.current_frame = cur + n_frames;
   ctx->time_bits = time_bits[n_frames - 1];
   ctx->have_time = true;
+  return RT_OK;
+}
+
+int rt_flush(rt_ctx* ctx) {
+  if (int rc = check(ctx)) return rc;
+  RT_FLUSH(ctx);  // launches, does not wait
   return RT_OK;
 }
 
@@ -762,6 +775,7 @@ int rt_sky_tile_stats(rt_ctx* ctx, uint32_t* sky_tiles, uint32_t* tiles) {
 int rt_accum_device_ptr(rt_ctx* ctx, void** dptr, size_t* bytes) {
   if (int rc = check(ctx)) return rc;
   if (!dptr || !bytes) return fail(RT_ERR_INVALID, "null out pointer");
+  RT_FLUSH(ctx);  // whoever asks for the address is about to look at the image: the recorded passes must be on the stream
   *dptr = ctx->accum;
   *bytes = ctx->accum_bytes;
   return RT_OK;

@@ -34,6 +34,10 @@ SIGNATURES = {
     "rth_app_ctx": (_VP, [_VP]),
     "rth_app_current_frame": (C.c_uint32, [_VP]),
     "rth_app_time_bits": (C.c_uint32, [_VP]),
+    "rth_app_camera_key": (C.c_int, [_VP, C.c_char_p]),
+    "rth_app_camera_zoom": (C.c_int, [_VP, C.c_float]),
+    "rth_app_camera_look_at_pixel": (C.c_int, [_VP, C.c_float, C.c_float]),
+    "rth_app_camera_get": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
     "rth_app_save_checkpoint": (C.c_int, [_VP, C.c_char_p]),
     "rth_app_load_checkpoint": (C.c_int, [_VP, C.c_char_p]),
     "rth_checkpoint_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -175,6 +179,29 @@ class App:
     @property
     def time_bits(self):
         return self._lib.rth_app_time_bits(self._h)
+
+    # the interactive controls on the App's own camera (each ends with scene_was_updated: frame 0, camera uploaded)
+    def key(self, name):
+        _check(self._lib.rth_app_camera_key(self._h, name.encode()))
+
+    def zoom(self, val):
+        _check(self._lib.rth_app_camera_zoom(self._h, val))
+
+    def look_at_pixel(self, off_x, off_y):
+        _check(self._lib.rth_app_camera_look_at_pixel(self._h, off_x, off_y))
+
+    def camera_raw(self):
+        out = np.zeros(1, CAMERA_DTYPE)
+        _check(self._lib.rth_app_camera_get(self._h, _p(out), None))
+        return out[0]
+
+    def read_rng_state(self):
+        out = np.empty((self.height, self.width), np.uint32)
+        _abi.check(_abi.load().rt_read_rng_state(self._lib.rth_app_ctx(self._h), _p(out), out.nbytes))
+        return out
+
+    def enable_rng_capture(self, on=True):
+        _abi.check(_abi.load().rt_enable_rng_capture(self._lib.rth_app_ctx(self._h), int(on)))
 
     def read_rgba8(self):
         out = np.empty((self.height, self.width, 4), np.uint8)

@@ -104,6 +104,10 @@ class Raytracer:
         t = np.ascontiguousarray(time_bits, dtype=np.uint32)
         check(self._lib.rt_render_frames_static(self._h, _ptr(t), t.shape[0]))
 
+    def flush(self):
+        """Launch recorded passes without waiting (queue.submit)."""
+        check(self._lib.rt_flush(self._h))
+
     def sync(self):
         check(self._lib.rt_sync(self._h))
 

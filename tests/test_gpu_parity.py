@@ -675,6 +675,139 @@ def test_deferred_passes_are_flushed_by_observers():
     rt.close()
 
 
+def _bound_image_setup(R, frames):
+    import torch
+
+    from raytracer_amd import dist as rdist
+
+    W, H, spp, flags = 96, 64, 2, O.ACCUM_F32
+    sp, mt = scenes.default_scene(1)
+    rt = R.Raytracer(W, H, flags)
+    rt.set_scene(sp, mt)
+    img = rdist.DeviceImage(rt, "cuda:0")
+    ref = O.OracleImage(W, H, flags)
+    O.render(ref, sp, mt, scenes.camera_raw(W, H, spp=spp, frames=frames), 0, frames)
+    tb = O.time_bits_table(frames)
+
+    def record(f):
+        rt.set_time(int(tb[f])); rt.set_camera(scenes.camera_raw(W, H, spp=spp, frames=frames, current_frame=f)); rt.compute()
+
+    return torch, rt, img, ref, record
+
+
+@pytest.mark.parametrize("how", ["accum_device_ptr", "flush"])
+def test_recorded_passes_reach_a_bound_image_without_an_observing_read(how):
+    """rt_compute only records (deferred passes). A caller that owns the image must see the finished picture after
+    rt_accum_device_ptr or rt_flush plus a device synchronisation of its own - no rt_sync, no rt_read_*."""
+    R = _rt()
+    torch, rt, img, ref, record = _bound_image_setup(R, 3)
+    for f in range(3):
+        record(f)
+    torch.cuda.synchronize()
+    assert not img.tensor.any().item(), "nothing has been launched yet: the passes are only recorded"
+    if how == "accum_device_ptr":
+        ptr, nbytes = rt.accum_device_ptr()  # launches the recorded passes
+        assert ptr == img.tensor.data_ptr() and nbytes == img.tensor.numel() * 4
+    else:
+        rt.flush()
+    torch.cuda.synchronize()
+    assert np.array_equal(img.tensor.cpu().numpy().view(np.uint32), ref.accum.view(np.uint32))
+    rt.bind_accum(0, 0)
+    rt.close()
+
+
+def test_passes_on_a_callers_stream_are_enqueued_by_rt_compute_itself():
+    """rt_set_stream: no deferral - work the caller enqueues on its stream after rt_compute runs after the pass."""
+    R = _rt()
+    torch, rt, img, ref, record = _bound_image_setup(R, 3)
+    stream = torch.cuda.Stream()
+    rt.set_stream(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        for f in range(3):
+            record(f)
+        copy = img.tensor.clone()  # enqueued on the same stream, after the three passes
+    stream.synchronize()
+    assert np.array_equal(copy.cpu().numpy().view(np.uint32), ref.accum.view(np.uint32))
+    rt.set_stream(0)
+    rt.bind_accum(0, 0)
+    rt.close()
+
+
+def test_headless_cli_per_frame_equals_batched(tmp_path):
+    """rt_headless --per-frame (App::update / App::render per redraw) renders what the batched run renders - also for
+    spp != 1, which needs the camera upload after --spp / --frames are applied (frame 0 used the constructor's)."""
+    import os, subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "rt_headless")
+    base = [exe, "--width", "96", "--height", "64", "--spp", "2", "--frames", "3", "--scene", "default", "--seed", "1"]
+    a, b = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    subprocess.run(base + ["--out", a], check=True, timeout=120, capture_output=True)
+    subprocess.run(base + ["--per-frame", "--out", b], check=True, timeout=120, capture_output=True)
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_headless_png_with_presentation_equals_the_oracle_through_the_screen_pass(tmp_path):
+    """rt_headless --present --out x.png on the GPU, decoded, against the ORACLE's RGBA8 image pushed
+    through the reference's screen pass on the CPU: pow(c, 2.2) (screen_shader.wgsl:36-39), then the sRGB encode of
+    the Bgra8UnormSrgb surface (render_env.rs:48). The plain PNG must equal the oracle's bytes exactly; the presented
+    one within 1/255 (two roundings: ours and the formula's)."""
+    import os, subprocess
+
+    from PIL import Image
+
+    from raytracer_amd import host
+
+    W, H, spp, frames = 128, 64, 2, 4
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "rt_headless")
+    base = [exe, "--width", str(W), "--height", str(H), "--spp", str(spp), "--frames", str(frames), "--scene", "default", "--seed", "1"]
+    plain, shown = str(tmp_path / "plain.png"), str(tmp_path / "shown.png")
+    subprocess.run(base + ["--out", plain], check=True, timeout=120, capture_output=True)
+    subprocess.run(base + ["--present", "--out", shown], check=True, timeout=120, capture_output=True)
+    sp, mt = host.scene_default(1)  # the scene the CLI builds (same seeded generator)
+    ref = O.OracleImage(W, H, 0)
+    O.render(ref, sp, mt, host.camera_raw(W, H, spp=spp, frames=frames), 0, frames)
+    assert ref.rgba8[..., :3].any()
+    assert np.array_equal(np.asarray(Image.open(plain).convert("RGBA")), ref.rgba8)
+    lin = (ref.rgba8[..., :3] / 255.0) ** 2.2
+    srgb = np.where(lin <= 0.0031308, 12.92 * lin, 1.055 * lin ** (1 / 2.4) - 0.055)
+    got = np.asarray(Image.open(shown).convert("RGB")).astype(int)
+    assert np.abs(got - np.rint(srgb * 255)).max() <= 1
+
+
+def test_moved_zoomed_host_camera_through_the_app_equals_the_oracle():
+    """the host mirror's Camera driven like the reference's (W / D / Space keys, zoom, look-at-pixel,
+    K for 2 spp: camera.rs:133-206), rendered by the host App on the GPU, bit for bit against the oracle fed THE
+    SAME 160 bytes - also after a second move mid-render (scene_was_updated restarts at frame 0 but keeps the image:
+    the reference never clears color_cache, and cw = 0 at frame 0 overwrites it)."""
+    R = _rt()
+    from raytracer_amd import host
+
+    W, H, frames = 160, 96, 3
+    sp, mt = host.scene_default(1)
+    app = host.App(W, H, R.RT_ACCUM_RGBA8, sp, mt, spp=1, frames=frames)
+    app.enable_rng_capture(True)
+    for k in ("W", "W", "D", "Space", "K"):  # forward twice, right, up; spp 1 -> 2
+        app.key(k)
+    app.zoom(1.5)
+    app.look_at_pixel(37.0, -11.0)
+    cam = app.camera_raw()
+    default = host.camera_raw(W, H, spp=2, frames=frames)
+    assert int(cam["samples_per_pixel"]) == 2 and int(cam["current_frame"]) == 0
+    assert not np.array_equal(cam["pixel_to_world"], default["pixel_to_world"]) and not np.array_equal(cam["pos"], default["pos"])
+    ref = O.OracleImage(W, H, 0)
+    app.redraw(frames)  # per-frame launches through App::update / App::render
+    _, tbits = O.render(ref, sp, mt, cam, 0, frames)
+    assert np.array_equal(app.read_rgba8(), ref.rgba8) and np.array_equal(app.read_rng_state(), ref.rng)
+    # move again mid-life: frame counter back to 0, time keeps running (time.rs is never reset)
+    app.key("A"); app.zoom(-0.5)
+    cam2 = app.camera_raw()
+    assert int(cam2["current_frame"]) == 0 and app.time_bits == tbits
+    app.run(frames)  # batched this time
+    O.render(ref, sp, mt, cam2, tbits, frames)
+    assert np.array_equal(app.read_rgba8(), ref.rgba8) and np.array_equal(app.read_rng_state(), ref.rng)
+    app.close()
+
+
 def test_sky_tiles_are_off_for_a_non_finite_camera(monkeypatch):
     """A non-finite pixel_to_world entry - even in the column the shader multiplies by 0.0 - makes every ray NaN, and
     NaN roots pass hit_sphere's range tests (wgsl:214-222): such rays hit. No tile may then be treated as sky."""
