@@ -92,7 +92,8 @@ struct rt_ctx {
   uint32_t sky_tiles_cap = 0;  // my_tiles the buffer is sized for
   uint32_t sky_key = 0;        // rank/world the flags were computed under
   bool sky_valid = false;
-  int use_sky = 1;             // env RT_SKY_TILES=0 traces every tile
+  int use_sky = 1;             // env RT_SKY_TILES=0 traces every tile (no tile masks at all)
+  int use_split = 1;           // env RT_SPLIT=0 keeps scenes of <= 32 spheres on the one-trace-per-iteration kernel
   int compute_units = 0;
   int waves_per_cu = 0;       // launch width override (0 = default); env RT_WAVES_PER_CU
   int reject_tries = 0;       // rejection rounds override (0 = default); env RT_REJECT_TRIES
@@ -293,8 +294,8 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     // the scratch is shared by every context on this GPU and keeps the last call's contents: the flags of this
     // context's my_tiles tiles are rewritten by every call (15 us at 4K)
     uint32_t* flags = reinterpret_cast<uint32_t*>(scratch + RT_STATIC_OFF_SKY);
-    RT_HIP(rt_launch_sky_tiles(a, flags, ctx->stream));
-    a.sky_flags = flags;
+    RT_HIP(rt_launch_tile_masks(a, flags, ctx->stream));
+    a.tile_masks = flags;
   } else if (ctx->use_sky && !ctx->counting) {
     if (ctx->sky_tiles_cap != my_tiles) {
       RT_HIP(hipStreamSynchronize(ctx->stream));
@@ -308,14 +309,16 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     if (ctx->sky_key != key) ctx->sky_valid = false;
     ctx->sky_key = key;
     if (!ctx->sky_valid) {
-      RT_HIP(rt_launch_sky_tiles(a, ctx->sky_flags, ctx->stream));
+      RT_HIP(rt_launch_tile_masks(a, ctx->sky_flags, ctx->stream));
       ctx->sky_valid = true;
     }
-    a.sky_flags = ctx->sky_flags;
+    a.tile_masks = ctx->sky_flags;
   }
   RT_HIP(hipMemsetAsync(a.queue, 0, sizeof(uint32_t), ctx->stream));
   if (timing) RT_HIP(hipEventRecord(e0, ctx->stream));
-  RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, ctx->stream));
+  // SPLIT variant (primary rays traced against their tile's candidate mask, primary + first bounce per iteration)
+  const bool split = ctx->use_split && a.tile_masks && !ctx->counting && a.n_spheres <= 32u;
+  RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, split, ctx->stream));
   if (timing) {
     RT_HIP(hipEventRecord(e1, ctx->stream));
     ctx->events_used++;
@@ -445,6 +448,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e5 = std::getenv("RT_STAGED_FRAMES")) c->use_staging = std::atoi(e5);
   if (const char* e6 = std::getenv("RT_SKY_TILES")) c->use_sky = std::atoi(e6);
   if (const char* e7 = std::getenv("RT_DEFER_FRAMES")) c->defer_max = std::atoi(e7);
+  if (const char* e8 = std::getenv("RT_SPLIT")) c->use_split = std::atoi(e8);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->static_time_host, RT_STATIC_MAX_FRAMES * sizeof(uint2), hipHostMallocDefault);
   if (e == hipSuccess) {
@@ -766,7 +770,7 @@ int rt_sky_tile_stats(rt_ctx* ctx, uint32_t* sky_tiles, uint32_t* tiles) {
   std::vector<uint32_t> h(ctx->sky_tiles_cap);
   RT_HIP(hipMemcpy(h.data(), ctx->sky_flags, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   uint32_t n = 0;
-  for (uint32_t f : h) n += f != 0u;
+  for (uint32_t f : h) n += f == 0u;  // mask 0 = no sphere can be hit
   *sky_tiles = n;
   *tiles = ctx->sky_tiles_cap;
   return RT_OK;

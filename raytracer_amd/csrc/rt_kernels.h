@@ -45,14 +45,16 @@ struct rt_kargs {
   uint32_t* queue;               // tile queue head, zeroed on the stream before every launch
   const uint32_t* tile_order;    // optional: permutation of [0, my_tiles): queue position -> tile
   uint32_t* tile_cost;           // optional: per-tile trace iterations of this launch (zeroed before it)
-  const uint32_t* sky_flags;     // optional: 1 per tile (of this rank) whose primary rays all miss (rt_sky_tiles_kernel)
+  const uint32_t* tile_masks;    // optional, per tile of this rank (rt_tile_masks_kernel): 0 = sky tile (no primary ray can hit a sphere),
+                                 // else the spheres its primary rays can hit (<= 32 spheres: bit cnt_pad-1-i; else all ones)
 };
 
 // n_waves persistent single-wave workgroups pull tiles from a.queue until a.my_tiles are handed out
-hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, hipStream_t stream);
+// split: the SPLIT variant (primary rays traced against their tile's mask; needs a.tile_masks, <= 32 spheres, !count)
+hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, bool split, hipStream_t stream);
 // folds the staged frame colours into the accumulation image, in frame order, for the pixels of this rank's tiles
 hipError_t rt_launch_combine_frames(const rt_kargs& a, hipStream_t stream);
-// flags[j] = 1 when no primary ray of this rank's j-th tile can hit a sphere (conservative, double precision)
-hipError_t rt_launch_sky_tiles(const rt_kargs& a, uint32_t* flags, hipStream_t stream);
+// masks[j] = spheres a primary ray of this rank's j-th tile can hit, 0 for a sky tile (conservative, double precision)
+hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, hipStream_t stream);
 hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t n, hipStream_t stream);
 hipError_t rt_launch_quantize(const void* src_f32x4, void* dst_rgba8, size_t n_pixels, hipStream_t stream);

@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "rt_kernels.h"
 
 namespace {
@@ -248,11 +250,15 @@ __device__ __forceinline__ uint32_t phase1_missbits(const_f32x16_ptr sph_p1, uin
 #define RT_PROFILE_SECTIONS 0
 #endif
 #if RT_PROFILE_SECTIONS
-#define RT_PROF_BEGIN(i) const unsigned long long prof_b##i = __builtin_amdgcn_s_memtime()
+#define RT_PROF_BEGIN(i) prof_b##i = __builtin_amdgcn_s_memtime()
 #define RT_PROF_END(i) prof_acc##i += __builtin_amdgcn_s_memtime() - prof_b##i
+#define RT_PROF_BEGIN_IF(c, i) if (c) prof_b##i = __builtin_amdgcn_s_memtime()
+#define RT_PROF_END_IF(c, i) if (c) prof_acc##i += __builtin_amdgcn_s_memtime() - prof_b##i
 #else
 #define RT_PROF_BEGIN(i)
 #define RT_PROF_END(i)
+#define RT_PROF_BEGIN_IF(c, i)
+#define RT_PROF_END_IF(c, i)
 #endif
 
 // One frame of store_color / combine_pixel_cache_color (wgsl:96-112) on the accumulation pixel `acc`, shared
@@ -278,12 +284,16 @@ __device__ __forceinline__ uint32_t combine_frame(float& acc0, float& acc1, floa
 }
 
 // the parked states are 1 and 2 (one unsigned compare), everything runnable is >= ST_READY
-enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_FRAME_END = 2, ST_READY = 3, ST_NEED_DIR = 4, ST_NEW_RAY = 5, ST_PATH_DONE = 6, ST_GOT_DIR = 7 };
+enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_FRAME_END = 2, ST_READY = 3, ST_NEED_DIR = 4, ST_NEW_RAY = 5, ST_PATH_DONE = 6, ST_GOT_DIR = 7,
+                  ST_PRIMARY = 8 /* SPLIT variants: a fresh primary ray, traced by [C-A] */ };
 
 // STRICT: arithmetic mode. COUNT: event counters for the roofline. SMALL: scenes of at most RT_SMALL_MAX spheres
 // (non-counting launches; chosen by rt_launch_path_kernel) - the per-sphere records of phase 2 and of the shading are
 // staged in LDS (a gather from LDS returns in ~100 cycles, from L1/L2 in several hundred: C2 strict -5 %, C3 -1 %), and
 // strict launches also drop spheres behind the ray in phase 1 (CULL).
+// SPLIT (SMALL scenes of at most 32 spheres whose launch has per-tile candidate masks): primary rays are traced by a
+// section of their own that takes the tile's mask as its candidates, and a lane can trace its primary ray and its first
+// bounce ray in one loop iteration (see [G] / [C] in the loop).
 // COLD KERNEL ARGUMENTS. Everything the per-pixel parts need (camera matrix, image geometry, buffers, frame
 // table) is read from the kernarg segment where it is used - behind a laundered pointer, so the compiler
 // cannot hoist the loads to the kernel entry and then keep ~40 scalar registers alive (and spilled into
@@ -295,13 +305,17 @@ __device__ __forceinline__ rt_kargs_cptr cold_args() {
   return p;
 }
 
-template <bool STRICT, bool COUNT, bool SMALL>
+template <bool STRICT, bool COUNT, bool SMALL, bool SPLIT>
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 6  // keeps the production variants at <= 80 VGPRs = 6 waves per SIMD (measured: C3 strict -2.7 %)
 #endif
 // The small-scene variants are held to 72 VGPRs = 7 waves per SIMD: big
 // images of small scenes gain 1-2 % from the seventh wave (profiles/r1e_ab_waves.log), the 1024-sphere scene loses 3 %.
-__global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_path_kernel(const rt_kargs a) {
+#ifndef RT_SPLIT_WAVES
+#define RT_SPLIT_WAVES 7
+#endif
+__global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7) : RT_MIN_WAVES) void rt_path_kernel(const rt_kargs a) {
+  static_assert(!SPLIT || (SMALL && !COUNT), "SPLIT needs the tile masks, which counting launches do not use");
   constexpr bool CULL = SMALL && STRICT;
   const uint32_t lane = threadIdx.x;
   const bool checker = (a.flags & RT_SHADE_CHECKER) != 0;
@@ -340,6 +354,8 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_p
   uint32_t my_tile = 0;      // index (in this rank's tile list) of the tile the pixel belongs to
   uint32_t iters = 0;        // trace iterations spent on the current pixel (cost feedback for the tile order)
   uint32_t q_tile = 0, q_tile_new = 0, q_frame = 0;  // wave-uniform: tile (and, staged, frame) being handed out
+  uint32_t q_mask = 0, q_mask_new = 0xffffffffu;     // wave-uniform: candidate mask of that tile (SPLIT)
+  uint32_t tmask = 0;                                // candidate spheres of the primary rays of this lane's pixel (SPLIT)
   float pcx = 0, pcy = 0, pcz = 0, pdx = 0, pdy = 0, pdz = 0;  // pixel_center, pixel_delta
   float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;                // accumulation pixel
   uint32_t k = 0, rng = 0, sample = 0, depth = 0;
@@ -349,9 +365,196 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_p
   float gqx = 0, gqy = 0, gqz = 0, gl2 = 1.0f;                 // accepted point of random_in_unit_sphere, |q|^2
 
 #if RT_PROFILE_SECTIONS
-  unsigned long long prof_acc0 = 0, prof_acc1 = 0, prof_acc2 = 0, prof_acc3 = 0, prof_acc4 = 0, prof_iters = 0, prof_p2_waves = 0, prof_p2_lanes = 0;
+  unsigned long long prof_acc0 = 0, prof_acc1 = 0, prof_acc2 = 0, prof_acc3 = 0, prof_acc4 = 0, prof_acc5 = 0, prof_iters = 0, prof_p2_waves = 0, prof_p2_lanes = 0;
+  unsigned long long prof_b0 = 0, prof_b1 = 0, prof_b2 = 0, prof_b3 = 0, prof_b4 = 0, prof_b5 = 0;
   const unsigned long long prof_start = __builtin_amdgcn_s_memtime(), prof_rstart = __builtin_amdgcn_s_memrealtime();
 #endif
+  // ---- trace (wgsl:182-231) + miss / scatter (wgsl:144-172) for the lanes whose state says so ----
+  // PRIMARY = false: lanes in ST_READY, the two-phase hit loop over all spheres.
+  // PRIMARY = true (SPLIT variants): lanes in ST_PRIMARY. Their candidates are the tile's mask (rt_tile_masks_kernel:
+  // every sphere outside the mask is a certain miss of every primary ray of the tile IN THE LITERAL ARITHMETIC, so
+  // leaving it out changes nothing - hit_sphere has no side effect when it returns false); no phase 1, no filter terms.
+  auto trace_and_shade = [&](auto primary_tag) __attribute__((always_inline)) {
+    constexpr bool PRIMARY = decltype(primary_tag)::value;
+    if (COUNT && !PRIMARY && __ballot(state == ST_READY)) c_wt++;
+    if (state == (PRIMARY ? ST_PRIMARY : ST_READY)) {
+      if (!PRIMARY) { RT_PROF_BEGIN(1); }
+      RT_PROF_BEGIN_IF(PRIMARY, 5);
+      iters++;
+      float closest = RT_RAY_TMAX;
+      int hit = -1;
+      // ---- per-ray terms of the phase-1 filter (DESIGN.md, "phase-1 filter") ----
+      // exact discriminant D = hb^2 - a (|o - c|^2 - r^2), hb = o.d - c.d. With the margin
+      // M = m a (|o|^2 + |c|^2 + r^2), m = RT_P1_MARGIN:
+      //   D + M = (o.d - c.d)^2 + [(m - 1) a |o|^2] + (2 a o).c - a K',  K' = (|c|^2 - r^2) - m (|c|^2 + r^2)
+      // K' is a per-sphere constant (rt_set_scene), everything else per-ray: 8 FMAs per sphere. The
+      // computed value and the oracle's literal discriminant each stay within 51 resp. 54 units of
+      // 2^-24 a (|o|^2 + |c|^2 + r^2) of D while all magnitudes are `tame` (no overflow / underflow);
+      // m = 2^-16 = 256 such units, so a negative sign here is a certain miss of the literal code too.
+      // Rays or scenes outside the tame range skip the filter (every sphere is a candidate).
+      const float a_fast = dot_fast(dx, dy, dz, dx, dy, dz);
+      const float oo = dot_fast(ox, oy, oz, ox, oy, oz);
+      const bool tame = a.p1_tame != 0u && a_fast >= 0x1p-20f && a_fast <= 0x1p20f && oo <= 0x1p40f;
+      p1_ray p1q = {};
+      if (!PRIMARY) {
+        const float nod = -dot_fast(ox, oy, oz, dx, dy, dz);
+        const float na = -a_fast;
+        const float nA = (a_fast * oo) * (RT_P1_MARGIN - 1.0f);
+        const float a2 = a_fast + a_fast;
+        p1q = p1_ray{f32x2{dx, dy}, f32x2{dz, nod}, f32x2{na, nA}, f32x2{a2 * ox, a2 * oy}, f32x2{a2 * oz, 0.0f}};
+      }
+      float a_lit = a_fast, inv_a = 0.0f;
+      rn_divisor a_div = {1.0f, 1.0f, false};
+      if (STRICT) {
+        const float len = sqrt_rn(dot_strict(dx, dy, dz, dx, dy, dz));
+        a_lit = len * len;  // length_squared (wgsl:306-309)
+        a_div = make_divisor(a_lit);
+      } else {
+        inv_a = __builtin_amdgcn_rcpf(a_fast);
+      }
+      // STRICT roots (-hb -+ sq) / a_lit of a tame ray: |hb|, sq < 2^32 and a_lit in [2^-21, 2^21], so the numerator
+      // is below div_core's upper limit, and a numerator under its lower limit 2^-60 gives |quotient| < 2^-38 both
+      // exactly and from div_core - far below RT_RAY_TMIN, where only the comparison `root <= tmin` is used.
+      // Untamed rays take the compiler's division.
+      const unsigned long long any_untame = __ballot(!tame);
+      const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
+      if (COUNT) { c_R++; c_T += n_spheres; }
+      if (!PRIMARY) { RT_PROF_END(1); }
+      for (uint32_t base = 0; base < (PRIMARY ? 1u : n_spheres); base += 32u) {
+        const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
+        // ---- phase 1: sign of D + M for spheres base..base+cnt-1 -> bitmask ----
+        // bit (cnt_pad-1-j) of `missbits` = sign of sphere (base+j)'s value (1 = certain miss)
+        const uint32_t cnt_pad = (cnt + 3u) & ~3u;
+        uint32_t cand;
+        if (PRIMARY) {
+          cand = tmask;  // same bit layout; rt_tile_masks_kernel sets no bit outside `valid`
+        } else {
+          RT_PROF_BEGIN(2);
+          const uint32_t missbits = phase1_missbits<CULL>(sph_p1, base, cnt_pad, p1q);
+#if RT_PROFILE_SECTIONS
+          asm volatile("" :: "v"(missbits));  // keep the loop inside the timed region
+#endif
+          RT_PROF_END(2);
+          // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
+          // (untamed rays take every sphere; the lowest cnt_pad - cnt bits are padding spheres)
+          const uint32_t valid = (cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u);  // wave-uniform
+          cand = (~missbits | untame_fill) & valid;
+        }
+        if (!PRIMARY) { RT_PROF_BEGIN(3); }
+        while (cand) {
+#if RT_PROFILE_SECTIONS
+          if (!PRIMARY) { prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true)); }
+#endif
+          const uint32_t lz = (uint32_t)__builtin_clz(cand);
+          cand &= ~(0x80000000u >> lz);
+          const uint32_t i = base + cnt_pad - 32u + lz;
+          const f32x4 s = SMALL ? sph_lds[i] : a.sph_test[i];
+          const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+          if (STRICT) {
+            // hit_sphere (wgsl:200-231), literal
+            const float hb = dot_strict(ocx, ocy, ocz, dx, dy, dz);
+            const float len = sqrt_rn(dot_strict(ocx, ocy, ocz, ocx, ocy, ocz));
+            const float c = len * len - s.w;
+            const float disc = hb * hb - a_lit * c;
+            if (!(disc < 0.0f)) {
+              if (COUNT) c_D++;
+              const float sq = sqrt_rn(disc);
+              float root = div_known(-hb - sq, a_div, !tame, any_untame);
+              bool ok = true;
+              if (root <= RT_RAY_TMIN || closest <= root) {
+                root = div_known(-hb + sq, a_div, !tame, any_untame);
+                if (root <= RT_RAY_TMIN || closest <= root) ok = false;
+              }
+              if (ok) { closest = root; hit = (int)i; }
+            }
+          } else {
+            const float hb = dot_fast(ocx, ocy, ocz, dx, dy, dz);
+            const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
+            const float disc = __builtin_fmaf(-a_fast, cc, hb * hb);
+            if (!(disc < 0.0f)) {  // the filter's margin lets a few near misses through
+              if (COUNT) c_D++;
+              const float sq = __builtin_amdgcn_sqrtf(disc);
+              const float r0 = (-hb - sq) * inv_a, r1 = (-hb + sq) * inv_a;
+              const bool ok0 = r0 > RT_RAY_TMIN && r0 < closest;
+              const float root = ok0 ? r0 : r1;
+              if (root > RT_RAY_TMIN && root < closest) { closest = root; hit = (int)i; }
+            }
+          }
+        }
+        if (!PRIMARY) { RT_PROF_END(3); }
+      }
+
+      if (!PRIMARY) { RT_PROF_BEGIN(4); }
+      if (hit < 0) {
+        // miss (wgsl:144-148); ray_color: color += miss * reflectance; break
+        if (COUNT) c_M++;
+        if (!checker) {
+          const float t = 0.5f * (1.0f - dy);
+          const float it = 1.0f - t;
+          colx = colx + (it + t * 0.5f) * refl;
+          coly = coly + (it + t * 0.7f) * refl;
+          colz = colz + (it + t * 1.0f) * refl;
+        } else {
+          colx = colx + 0.0f * refl; coly = coly + 0.0f * refl; colz = colz + 0.0f * refl;
+        }
+        state = ST_PATH_DONE;
+      } else {
+        if (COUNT) { c_H++; c_S++; }
+        const f32x4 sg = SMALL ? sph_lds[RT_SMALL_MAX + (uint32_t)hit] : a.sph_shade[hit];      // {cx, cy, cz, r}
+        const f32x4 sc = SMALL ? sph_lds[2u * RT_SMALL_MAX + (uint32_t)hit] : a.sph_col[hit];   // {material r, g, b, +-1/r}
+        // hit record of the closest sphere (wgsl:225-227): point = ray_at(t), normal = (point - c) / r
+        float px, py, pz, nx, ny, nz;
+        if (STRICT) {
+          px = ox + closest * dx; py = oy + closest * dy; pz = oz + closest * dz;
+          const float ex = px - sg.x, ey = py - sg.y, ez = pz - sg.z;
+          if (sc.w > 0.0f) {
+            // r is a power of two (rt_set_scene marks that with a positive 1/r): x / r == x * (1/r)
+            // exactly, barring overflow/underflow of a unit-length normal's components
+            nx = ex * sc.w; ny = ey * sc.w; nz = ez * sc.w;
+          } else {
+            const rn_divisor rd = make_divisor(sg.w);
+            div3_rn(ex, ey, ez, rd, nx, ny, nz);
+          }
+        } else {
+          px = __builtin_fmaf(closest, dx, ox); py = __builtin_fmaf(closest, dy, oy); pz = __builtin_fmaf(closest, dz, oz);
+          const float ir = __builtin_fabsf(sc.w);
+          nx = (px - sg.x) * ir; ny = (py - sg.y) * ir; nz = (pz - sg.z) * ir;
+        }
+        // scatter (wgsl:150-168)
+        float kk = (1.0f - RT_LOCAL_REFLECTANCE) * refl;
+        if (checker) {
+          const float fx = __builtin_floorf(4.0f * nx);
+          const float fy = __builtin_floorf(4.0f * ny + 0.5f);
+          const float h = (fx + fy) * 0.5f;
+          kk = (h == __builtin_floorf(h)) ? refl : 0.0f;
+        }
+        colx = colx + sc.x * kk; coly = coly + sc.y * kk; colz = colz + sc.z * kk;
+        refl = refl * RT_LOCAL_REFLECTANCE;
+        ox = px; oy = py; oz = pz;
+        depth++;
+        if ((hit & 1) == 0) {
+          // reflection (wgsl:170-172): dir - 2*dot(dir, n)*n
+          if (COUNT) c_Sm++;
+          if (STRICT) {
+            const float k2 = 2.0f * dot_strict(dx, dy, dz, nx, ny, nz);
+            dx = dx - k2 * nx; dy = dy - k2 * ny; dz = dz - k2 * nz;
+          } else {
+            const float k2 = -2.0f * dot_fast(dx, dy, dz, nx, ny, nz);
+            dx = __builtin_fmaf(k2, nx, dx); dy = __builtin_fmaf(k2, ny, dy); dz = __builtin_fmaf(k2, nz, dz);
+          }
+          state = depth > (uint32_t)RT_MAX_RAY_DEPTH ? ST_PATH_DONE : ST_READY;
+        } else {
+          // normal + random_unit_vector(): the direction is drawn in [G]; park the normal in d
+          if (COUNT) c_Sd++;
+          dx = nx; dy = ny; dz = nz;
+          state = ST_NEED_DIR;
+        }
+      }
+      if (!PRIMARY) { RT_PROF_END(4); }
+      RT_PROF_END_IF(PRIMARY, 5);
+    }
+  };
+
   for (;;) {
 #if RT_PROFILE_SECTIONS
     prof_iters++;
@@ -445,9 +648,11 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_p
           q_frame_new = 0;
           if (ca->staging) { slot = base / ca->n_frames; q_frame_new = base - slot * ca->n_frames; }
           q_tile_new = ca->tile_order ? ca->tile_order[slot] : slot;
-          if (COUNT || !ca->sky_flags || __builtin_amdgcn_readfirstlane(ca->sky_flags[q_tile_new]) == 0u) break;
+          // tile_masks[tile]: 0 = sky tile, else the spheres a primary ray of the tile can hit (SPLIT; all ones otherwise)
+          q_mask_new = 0xffffffffu;
+          if (COUNT || !ca->tile_masks || (q_mask_new = __builtin_amdgcn_readfirstlane(ca->tile_masks[q_tile_new])) != 0u) break;
           // ---- SKY TILE, finished right here by all 64 lanes (lane = pixel, no divergence; the lanes' own paths
-          // wait): rt_sky_tiles_kernel proved that every primary ray of this tile misses every sphere in the literal
+          // wait): rt_tile_masks_kernel proved that every primary ray of this tile misses every sphere in the literal
           // arithmetic ("sky tiles"). Each sample is then get_random_ray's two draws and the miss
           // colour (wgsl:174-180, 144-148, 131-134) - no trace.
           const uint32_t tile = q_tile_new * ca->world + ca->rank;
@@ -520,7 +725,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_p
       if (wants && my < avail) {  // a pixel of the tile already staged in LDS
         const uint32_t w = (q_cur + my) & 63u;
         rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
-        my_tile = q_tile; k = q_frame;
+        my_tile = q_tile; k = q_frame; tmask = q_mask;
         got = true;
       }
       if (n_need > avail) {
@@ -551,10 +756,10 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_p
           if (wants && !got) {
             const uint32_t w = my - avail;
             rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
-            my_tile = q_tile_new; k = q_frame_new;
+            my_tile = q_tile_new; k = q_frame_new; tmask = q_mask_new;
             got = true;
           }
-          q_tile = q_tile_new; q_frame = q_frame_new;
+          q_tile = q_tile_new; q_frame = q_frame_new; q_mask = q_mask_new;
           q_cur = base * 64u + (n_need - avail);
           q_end = base * 64u + 64u;
         } else {
@@ -596,11 +801,20 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_p
     }  // service
     }  // parked
 
-    // ================= [G] random draws =================
-    // Round 0 is shared: lanes starting a sample draw the two jitter numbers of get_random_ray
-    // (wgsl:174-180) with the same instructions that give lanes in random_in_unit_sphere
-    // (wgsl:281-290) the first two of their three numbers. Further rounds serve NEED_DIR only.
+    // ================= [G] random draws, [C] trace + shade =================
+    // Two loop shapes. The classic one (one trace per iteration): round 0 of the draws is shared - lanes starting a
+    // sample draw the two jitter numbers of get_random_ray (wgsl:174-180) with the same instructions that give lanes
+    // in random_in_unit_sphere (wgsl:281-290) the first two of their three numbers - then further rounds for NEED_DIR,
+    // then ONE trace for every lane that has a ray.
+    // The SPLIT one (scenes of <= 32 spheres with per-tile candidate masks, DESIGN.md "primary / bounce split"): a lane
+    // can trace its PRIMARY ray and, when that hits, its first BOUNCE ray in the same iteration:
+    //   [G0] NEW_RAY lanes draw the jitter -> [C-A] primary trace: candidates are the tile's mask, no phase 1, no
+    //   filter terms -> shade -> [G1] rejection rounds for every lane that needs a direction (from [C-A] just now or
+    //   from [C-B] of the previous iteration) -> [C-B] the general trace (phase 1 + phase 2) -> shade.
+    // Rays per lane and iteration rise from 0.92 to ~1.6 on the 20-sphere scene, the rounds and the bookkeeping
+    // sections are paid once per iteration as before, and primary rays (43 % of the rays there) skip phase 1.
     RT_PROF_BEGIN(0);
+    if (!SPLIT) {
     if (state == ST_NEW_RAY || state == ST_NEED_DIR) {
       uint32_t s0, s1;
       RT_STEP(s0); RT_STEP(s1);
@@ -625,10 +839,26 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_p
       }
     }
     if (COUNT) c_wr++;
+    } else {
+      // [G0] get_random_ray (wgsl:174-180) for the lanes that start a sample
+      if (state == ST_NEW_RAY) {
+        uint32_t s0, s1;
+        RT_STEP(s0); RT_STEP(s1);
+        const float px = rng_jitter(s0), py = rng_jitter(s1);
+        dx = pcx + px * pdx; dy = pcy + py * pdy; dz = pcz + 1.0f * pdz;
+        ox = a.pos[0]; oy = a.pos[1]; oz = a.pos[2];
+        colx = coly = colz = 0.0f; refl = 1.0f; depth = 0;
+        state = ST_PRIMARY;
+      }
+      RT_PROF_END(0);
+      // [C-A] primary rays: the tile's candidate mask instead of phase 1
+      trace_and_shade(std::integral_constant<bool, true>{});
+      RT_PROF_BEGIN(0);
+    }
 #ifndef RT_ROUND_MIN_LANES
 #define RT_ROUND_MIN_LANES 1u  // a further round runs while at least this many lanes still need a direction
 #endif
-    for (uint32_t round = 1; round < a.reject_tries && (uint32_t)__popcll(__ballot(state == ST_NEED_DIR)) >= RT_ROUND_MIN_LANES; ++round) {
+    for (uint32_t round = SPLIT ? 0u : 1u; round < a.reject_tries && (uint32_t)__popcll(__ballot(state == ST_NEED_DIR)) >= RT_ROUND_MIN_LANES; ++round) {
       if (COUNT) c_wr++;
       if (state == ST_NEED_DIR) {
         uint32_t s0, s1, s2;
@@ -659,174 +889,8 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_p
     }
 
     RT_PROF_END(0);
-    // ================= [C] trace + shade (lanes with a ray) =================
-    if (COUNT && __ballot(state == ST_READY)) c_wt++;
-    if (state == ST_READY) {
-      RT_PROF_BEGIN(1);
-      iters++;
-      float closest = RT_RAY_TMAX;
-      int hit = -1;
-      // ---- per-ray terms of the phase-1 filter (DESIGN.md, "phase-1 filter") ----
-      // exact discriminant D = hb^2 - a (|o - c|^2 - r^2), hb = o.d - c.d. With the margin
-      // M = m a (|o|^2 + |c|^2 + r^2), m = RT_P1_MARGIN:
-      //   D + M = (o.d - c.d)^2 + [(m - 1) a |o|^2] + (2 a o).c - a K',  K' = (|c|^2 - r^2) - m (|c|^2 + r^2)
-      // K' is a per-sphere constant (rt_set_scene), everything else per-ray: 8 FMAs per sphere. The
-      // computed value and the oracle's literal discriminant each stay within 51 resp. 54 units of
-      // 2^-24 a (|o|^2 + |c|^2 + r^2) of D while all magnitudes are `tame` (no overflow / underflow);
-      // m = 2^-16 = 256 such units, so a negative sign here is a certain miss of the literal code too.
-      // Rays or scenes outside the tame range skip the filter (every sphere is a candidate).
-      const float a_fast = dot_fast(dx, dy, dz, dx, dy, dz);
-      const float oo = dot_fast(ox, oy, oz, ox, oy, oz);
-      const float nod = -dot_fast(ox, oy, oz, dx, dy, dz);
-      const bool tame = a.p1_tame != 0u && a_fast >= 0x1p-20f && a_fast <= 0x1p20f && oo <= 0x1p40f;
-      const float na = -a_fast;
-      const float nA = (a_fast * oo) * (RT_P1_MARGIN - 1.0f);
-      const float a2 = a_fast + a_fast;
-      const p1_ray p1q = {f32x2{dx, dy}, f32x2{dz, nod}, f32x2{na, nA}, f32x2{a2 * ox, a2 * oy}, f32x2{a2 * oz, 0.0f}};
-      float a_lit = a_fast, inv_a = 0.0f;
-      rn_divisor a_div = {1.0f, 1.0f, false};
-      if (STRICT) {
-        const float len = sqrt_rn(dot_strict(dx, dy, dz, dx, dy, dz));
-        a_lit = len * len;  // length_squared (wgsl:306-309)
-        a_div = make_divisor(a_lit);
-      } else {
-        inv_a = __builtin_amdgcn_rcpf(a_fast);
-      }
-      // STRICT roots (-hb -+ sq) / a_lit of a tame ray: |hb|, sq < 2^32 and a_lit in [2^-21, 2^21], so the numerator
-      // is below div_core's upper limit, and a numerator under its lower limit 2^-60 gives |quotient| < 2^-38 both
-      // exactly and from div_core - far below RT_RAY_TMIN, where only the comparison `root <= tmin` is used.
-      // Untamed rays take the compiler's division.
-      const unsigned long long any_untame = __ballot(!tame);
-      const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
-      if (COUNT) { c_R++; c_T += n_spheres; }
-      RT_PROF_END(1);
-      for (uint32_t base = 0; base < n_spheres; base += 32u) {
-        const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
-        // ---- phase 1: sign of D + M for spheres base..base+cnt-1 -> bitmask ----
-        // bit (cnt_pad-1-j) of `missbits` = sign of sphere (base+j)'s value (1 = certain miss)
-        const uint32_t cnt_pad = (cnt + 3u) & ~3u;
-        RT_PROF_BEGIN(2);
-        const uint32_t missbits = phase1_missbits<CULL>(sph_p1, base, cnt_pad, p1q);
-#if RT_PROFILE_SECTIONS
-        asm volatile("" :: "v"(missbits));  // keep the loop inside the timed region
-#endif
-        RT_PROF_END(2);
-        RT_PROF_BEGIN(3);
-        // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
-        // (untamed rays take every sphere; the lowest cnt_pad - cnt bits are padding spheres)
-        const uint32_t valid = (cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u);  // wave-uniform
-        uint32_t cand = (~missbits | untame_fill) & valid;
-        while (cand) {
-#if RT_PROFILE_SECTIONS
-          prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true));
-#endif
-          const uint32_t lz = (uint32_t)__builtin_clz(cand);
-          cand &= ~(0x80000000u >> lz);
-          const uint32_t i = base + cnt_pad - 32u + lz;
-          const f32x4 s = SMALL ? sph_lds[i] : a.sph_test[i];
-          const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
-          if (STRICT) {
-            // hit_sphere (wgsl:200-231), literal
-            const float hb = dot_strict(ocx, ocy, ocz, dx, dy, dz);
-            const float len = sqrt_rn(dot_strict(ocx, ocy, ocz, ocx, ocy, ocz));
-            const float c = len * len - s.w;
-            const float disc = hb * hb - a_lit * c;
-            if (!(disc < 0.0f)) {
-              if (COUNT) c_D++;
-              const float sq = sqrt_rn(disc);
-              float root = div_known(-hb - sq, a_div, !tame, any_untame);
-              bool ok = true;
-              if (root <= RT_RAY_TMIN || closest <= root) {
-                root = div_known(-hb + sq, a_div, !tame, any_untame);
-                if (root <= RT_RAY_TMIN || closest <= root) ok = false;
-              }
-              if (ok) { closest = root; hit = (int)i; }
-            }
-          } else {
-            const float hb = dot_fast(ocx, ocy, ocz, dx, dy, dz);
-            const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
-            const float disc = __builtin_fmaf(-a_fast, cc, hb * hb);
-            if (!(disc < 0.0f)) {  // the filter's margin lets a few near misses through
-              if (COUNT) c_D++;
-              const float sq = __builtin_amdgcn_sqrtf(disc);
-              const float r0 = (-hb - sq) * inv_a, r1 = (-hb + sq) * inv_a;
-              const bool ok0 = r0 > RT_RAY_TMIN && r0 < closest;
-              const float root = ok0 ? r0 : r1;
-              if (root > RT_RAY_TMIN && root < closest) { closest = root; hit = (int)i; }
-            }
-          }
-        }
-        RT_PROF_END(3);
-      }
-
-      RT_PROF_BEGIN(4);
-      if (hit < 0) {
-        // miss (wgsl:144-148); ray_color: color += miss * reflectance; break
-        if (COUNT) c_M++;
-        if (!checker) {
-          const float t = 0.5f * (1.0f - dy);
-          const float it = 1.0f - t;
-          colx = colx + (it + t * 0.5f) * refl;
-          coly = coly + (it + t * 0.7f) * refl;
-          colz = colz + (it + t * 1.0f) * refl;
-        } else {
-          colx = colx + 0.0f * refl; coly = coly + 0.0f * refl; colz = colz + 0.0f * refl;
-        }
-        state = ST_PATH_DONE;
-      } else {
-        if (COUNT) { c_H++; c_S++; }
-        const f32x4 sg = SMALL ? sph_lds[RT_SMALL_MAX + (uint32_t)hit] : a.sph_shade[hit];      // {cx, cy, cz, r}
-        const f32x4 sc = SMALL ? sph_lds[2u * RT_SMALL_MAX + (uint32_t)hit] : a.sph_col[hit];   // {material r, g, b, +-1/r}
-        // hit record of the closest sphere (wgsl:225-227): point = ray_at(t), normal = (point - c) / r
-        float px, py, pz, nx, ny, nz;
-        if (STRICT) {
-          px = ox + closest * dx; py = oy + closest * dy; pz = oz + closest * dz;
-          const float ex = px - sg.x, ey = py - sg.y, ez = pz - sg.z;
-          if (sc.w > 0.0f) {
-            // r is a power of two (rt_set_scene marks that with a positive 1/r): x / r == x * (1/r)
-            // exactly, barring overflow/underflow of a unit-length normal's components
-            nx = ex * sc.w; ny = ey * sc.w; nz = ez * sc.w;
-          } else {
-            const rn_divisor rd = make_divisor(sg.w);
-            div3_rn(ex, ey, ez, rd, nx, ny, nz);
-          }
-        } else {
-          px = __builtin_fmaf(closest, dx, ox); py = __builtin_fmaf(closest, dy, oy); pz = __builtin_fmaf(closest, dz, oz);
-          const float ir = __builtin_fabsf(sc.w);
-          nx = (px - sg.x) * ir; ny = (py - sg.y) * ir; nz = (pz - sg.z) * ir;
-        }
-        // scatter (wgsl:150-168)
-        float kk = (1.0f - RT_LOCAL_REFLECTANCE) * refl;
-        if (checker) {
-          const float fx = __builtin_floorf(4.0f * nx);
-          const float fy = __builtin_floorf(4.0f * ny + 0.5f);
-          const float h = (fx + fy) * 0.5f;
-          kk = (h == __builtin_floorf(h)) ? refl : 0.0f;
-        }
-        colx = colx + sc.x * kk; coly = coly + sc.y * kk; colz = colz + sc.z * kk;
-        refl = refl * RT_LOCAL_REFLECTANCE;
-        ox = px; oy = py; oz = pz;
-        depth++;
-        if ((hit & 1) == 0) {
-          // reflection (wgsl:170-172): dir - 2*dot(dir, n)*n
-          if (COUNT) c_Sm++;
-          if (STRICT) {
-            const float k2 = 2.0f * dot_strict(dx, dy, dz, nx, ny, nz);
-            dx = dx - k2 * nx; dy = dy - k2 * ny; dz = dz - k2 * nz;
-          } else {
-            const float k2 = -2.0f * dot_fast(dx, dy, dz, nx, ny, nz);
-            dx = __builtin_fmaf(k2, nx, dx); dy = __builtin_fmaf(k2, ny, dy); dz = __builtin_fmaf(k2, nz, dz);
-          }
-          state = depth > (uint32_t)RT_MAX_RAY_DEPTH ? ST_PATH_DONE : ST_READY;
-        } else {
-          // normal + random_unit_vector(): the direction is drawn in [G]; park the normal in d
-          if (COUNT) c_Sd++;
-          dx = nx; dy = ny; dz = nz;
-          state = ST_NEED_DIR;
-        }
-      }
-      RT_PROF_END(4);
-    }
+    // ================= [C] / [C-B] trace + shade (lanes with a ray) =================
+    trace_and_shade(std::integral_constant<bool, false>{});
   }
 
   const rt_kargs_cptr ca = cold_args();
@@ -842,8 +906,8 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? 7 : RT_MIN_WAVES) void rt_p
     atomicMax(&ca->counters[9], prof_rstart + rlife);
     atomicAdd(&ca->counters[10], prof_rstart & 0xffffffffull);
     atomicAdd(&ca->counters[11], (prof_rstart + rlife) & 0xffffffffull);
-    atomicAdd(&ca->counters[12], prof_p2_lanes);  // phase-2 loop: lane-iterations
-    atomicAdd(&ca->counters[13], prof_p2_waves);  // phase-2 loop: wave-iterations
+    atomicAdd(&ca->counters[12], SPLIT ? prof_acc5 : prof_p2_lanes);  // SPLIT: cycles in [C-A]; else phase-2 loop: lane-iterations
+    atomicAdd(&ca->counters[13], prof_p2_waves);  // phase-2 loop ([C-B]): wave-iterations
   }
 #endif
   if (COUNT) {
@@ -889,10 +953,13 @@ __global__ __launch_bounds__(256) void rt_combine_frames_kernel(const rt_kargs a
   }
 }
 
-// SKY TILES ("sky tiles"): flags[j] = 1 when EVERY primary ray the pixels of this rank's j-th 8x8 tile can draw
-// is a certain miss of EVERY sphere in the literal arithmetic of hit_sphere (wgsl:200-231), so that the path kernel may
-// finish the tile without tracing. A sufficient condition, evaluated in double precision with margins far above the
-// f32 rounding of the literal code; a tile that fails it is simply traced.
+// TILE MASKS ("sky tiles" and "primary / bounce split"): masks[j] says which spheres a primary ray of this
+// rank's j-th 8x8 tile can hit. Sphere i is LEFT OUT when EVERY primary ray the pixels of the tile can draw is a certain
+// miss of it in the literal arithmetic of hit_sphere (wgsl:200-231). A sufficient condition per sphere, evaluated in
+// double precision with margins far above the f32 rounding of the literal code; a sphere that fails it stays a candidate
+// and gets the exact test. masks[j] == 0: a SKY TILE, which the path kernel finishes without tracing. Scenes of at
+// most 32 spheres get the mask in the bit layout of the path kernel's candidate walk (sphere i = bit cnt_pad-1-i,
+// cnt_pad = n rounded up to 4), larger scenes only 0 / all ones.
 //   directions of the tile: d = c0 u + c1 (H - v) + c3 + (px dx, py dy, dz), u, v over the 8x8 pixels, px, py in [-.5, .5)
 //   (wgsl:85-94,174-180; c0, c1, c3 columns of pixel_to_world, delta = c0 - c1): a ball of radius rho around dc.
 //   Per sphere (centre c, radius r, seen from the origin o at distance L under the angle psi against dc), with
@@ -902,7 +969,7 @@ __global__ __launch_bounds__(256) void rt_combine_frames_kernel(const rt_kargs a
 //        discriminant is below -2^-12 a S and the literal one (within 54 2^-24 a S of it) is negative; or
 //   (B)  cos(psi - theta) < -2^-8: the sphere lies behind every ray, literal half_b > 0 and c > 0, both roots <= 0 <= tmin.
 //   Rays must be `tame` (no overflow / underflow in the literal code): |d|^2 in [2^-19, 2^19], |o|^2 <= 2^39, tame scene.
-__global__ __launch_bounds__(256) void rt_sky_tiles_kernel(const rt_kargs a, uint32_t* __restrict__ flags) {
+__global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, uint32_t* __restrict__ masks) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= a.my_tiles) return;
   const uint32_t tile = j * a.world + a.rank;
@@ -929,7 +996,12 @@ __global__ __launch_bounds__(256) void rt_sky_tiles_kernel(const rt_kargs a, uin
   float colsum = 0.0f;
   for (int i = 0; i < 16; ++i) colsum += a.p2w[i] * 0.0f;
   ok = ok && colsum == 0.0f;
+  const bool per_sphere = a.n_spheres <= 32u;
+  const uint32_t cnt_pad = per_sphere ? (a.n_spheres + 3u) & ~3u : 32u;
+  const uint32_t everything = per_sphere ? (cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - a.n_spheres)) - 1u) : 0xffffffffu;
+  uint32_t mask = everything;  // the rays are not provably tame: every sphere stays a candidate
   if (ok) {  // also false for NaN / inf in the columns used above
+    mask = 0u;
     const double sin_t = rho / ndc, cos_t = sqrt(1.0 - sin_t * sin_t);
     for (uint32_t i = 0; i < a.n_spheres; ++i) {
       const rt_f32x4 sp = a.sph_shade[i];
@@ -946,10 +1018,13 @@ __global__ __launch_bounds__(256) void rt_sky_tiles_kernel(const rt_kargs a, uin
         const bool behind = cpsi * cos_t + sp1 * sin_t < -0x1p-8;  // cos(psi - theta)
         miss = clear || behind;
       }
-      if (!miss) { ok = false; break; }
+      if (!miss) {
+        if (!per_sphere) { mask = everything; break; }
+        mask |= 1u << (cnt_pad - 1u - i);
+      }
     }
   }
-  flags[j] = ok ? 1u : 0u;
+  masks[j] = mask;
 }
 
 // Tile order for the next launch: counting sort of this launch's per-tile cost, dearest first.
@@ -993,21 +1068,25 @@ __global__ void rt_quantize_kernel(const f32x4* __restrict__ src, uint32_t* __re
 
 }  // namespace
 
-hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, hipStream_t stream) {
+hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, bool split, hipStream_t stream) {
   if (n_waves == 0 || a.my_tiles == 0) return hipSuccess;
   const dim3 grid(n_waves), block(64);
+  // SPLIT needs what makes its primary section correct: candidate masks (<= 32 spheres, a non-counting launch)
+  if (split && (count || !a.tile_masks || a.n_spheres > 32u)) return hipErrorInvalidValue;
   // SMALL variants while the scene fits their LDS arrays. The behind cull they carry in strict mode saves exact tests
   // for one more instruction per sphere test (measured: 20 spheres -3 %, 1024 spheres +2 %). Counting launches keep
   // every candidate: the oracle's D counts their discriminants.
   const bool small = a.n_spheres <= RT_SMALL_MAX;
   if (strict) {
-    if (count) hipLaunchKernelGGL((rt_path_kernel<true, true, false>), grid, block, 0, stream, a);
-    else if (small) hipLaunchKernelGGL((rt_path_kernel<true, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((rt_path_kernel<true, false, false>), grid, block, 0, stream, a);
+    if (count) hipLaunchKernelGGL((rt_path_kernel<true, true, false, false>), grid, block, 0, stream, a);
+    else if (split) hipLaunchKernelGGL((rt_path_kernel<true, false, true, true>), grid, block, 0, stream, a);
+    else if (small) hipLaunchKernelGGL((rt_path_kernel<true, false, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((rt_path_kernel<true, false, false, false>), grid, block, 0, stream, a);
   } else {
-    if (count) hipLaunchKernelGGL((rt_path_kernel<false, true, false>), grid, block, 0, stream, a);
-    else if (small) hipLaunchKernelGGL((rt_path_kernel<false, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((rt_path_kernel<false, false, false>), grid, block, 0, stream, a);
+    if (count) hipLaunchKernelGGL((rt_path_kernel<false, true, false, false>), grid, block, 0, stream, a);
+    else if (split) hipLaunchKernelGGL((rt_path_kernel<false, false, true, true>), grid, block, 0, stream, a);
+    else if (small) hipLaunchKernelGGL((rt_path_kernel<false, false, true, false>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((rt_path_kernel<false, false, false, false>), grid, block, 0, stream, a);
   }
   return hipGetLastError();
 }
@@ -1019,9 +1098,9 @@ hipError_t rt_launch_combine_frames(const rt_kargs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t rt_launch_sky_tiles(const rt_kargs& a, uint32_t* flags, hipStream_t stream) {
+hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, hipStream_t stream) {
   if (a.my_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(rt_sky_tiles_kernel, dim3((a.my_tiles + 255u) / 256u), dim3(256), 0, stream, a, flags);
+  hipLaunchKernelGGL(rt_tile_masks_kernel, dim3((a.my_tiles + 255u) / 256u), dim3(256), 0, stream, a, masks);
   return hipGetLastError();
 }
 

@@ -826,7 +826,7 @@ def test_sky_tiles_are_off_for_a_non_finite_camera(monkeypatch):
 
 @pytest.mark.parametrize("knob,value", [("RT_REJECT_TRIES", "1"), ("RT_REJECT_TRIES", "5"), ("RT_BATCH_LANES", "1"), ("RT_BATCH_LANES", "9"),
                                         ("RT_WAVES_PER_CU", "3"), ("RT_WAVES_PER_CU", "32"), ("RT_STAGED_FRAMES", "0"),
-                                        ("RT_TILE_ORDER", "0"), ("RT_DEFER_FRAMES", "3")])
+                                        ("RT_TILE_ORDER", "0"), ("RT_DEFER_FRAMES", "3"), ("RT_SPLIT", "0"), ("RT_SKY_TILES", "0")])
 def test_launch_knobs_change_no_bit(knob, value, monkeypatch):
     """Launch width, rejection rounds per iteration, parked lanes per service, staging, tile order and the size of a
     deferred batch only move work between lanes and launches: each pixel consumes its own RNG stream in the
