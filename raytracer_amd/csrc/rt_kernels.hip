@@ -285,7 +285,7 @@ __device__ __forceinline__ uint32_t combine_frame(float& acc0, float& acc1, floa
 
 // the parked states are 1 and 2 (one unsigned compare), everything runnable is >= ST_READY
 enum : uint32_t { ST_DEAD = 0, ST_NEED_PIXEL = 1, ST_FRAME_END = 2, ST_READY = 3, ST_NEED_DIR = 4, ST_NEW_RAY = 5, ST_PATH_DONE = 6, ST_GOT_DIR = 7,
-                  ST_PRIMARY = 8 /* SPLIT variants: a fresh primary ray, traced by [C-A] */ };
+                  ST_TEST = 8 /* SPLIT variants: a ray whose candidates wait for the exact tests of [W] */ };
 
 // STRICT: arithmetic mode. COUNT: event counters for the roofline. SMALL: scenes of at most RT_SMALL_MAX spheres
 // (non-counting launches; chosen by rt_launch_path_kernel) - the per-sphere records of phase 2 and of the shading are
@@ -316,7 +316,9 @@ template <bool STRICT, bool COUNT, bool SMALL, bool SPLIT>
 #endif
 __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7) : RT_MIN_WAVES) void rt_path_kernel(const rt_kargs a) {
   static_assert(!SPLIT || (SMALL && !COUNT), "SPLIT needs the tile masks, which counting launches do not use");
-  constexpr bool CULL = SMALL && STRICT;
+  // behind cull: strict small-scene launches (fewer exact tests), and every SPLIT launch (there a bounce ray without
+  // candidates is finished on the spot, so candidates that only fall to the exact test cost a loop iteration)
+  constexpr bool CULL = SMALL && (STRICT || SPLIT);
   const uint32_t lane = threadIdx.x;
   const bool checker = (a.flags & RT_SHADE_CHECKER) != 0;
   const bool accum_f32 = (a.flags & RT_ACCUM_F32) != 0;
@@ -369,191 +371,225 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   unsigned long long prof_b0 = 0, prof_b1 = 0, prof_b2 = 0, prof_b3 = 0, prof_b4 = 0, prof_b5 = 0;
   const unsigned long long prof_start = __builtin_amdgcn_s_memtime(), prof_rstart = __builtin_amdgcn_s_memrealtime();
 #endif
-  // ---- trace (wgsl:182-231) + miss / scatter (wgsl:144-172) for the lanes whose state says so ----
-  // PRIMARY = false: lanes in ST_READY, the two-phase hit loop over all spheres.
-  // PRIMARY = true (SPLIT variants): lanes in ST_PRIMARY. Their candidates are the tile's mask (rt_tile_masks_kernel:
-  // every sphere outside the mask is a certain miss of every primary ray of the tile IN THE LITERAL ARITHMETIC, so
-  // leaving it out changes nothing - hit_sphere has no side effect when it returns false); no phase 1, no filter terms.
-  auto trace_and_shade = [&](auto primary_tag) __attribute__((always_inline)) {
-    constexpr bool PRIMARY = decltype(primary_tag)::value;
-    if (COUNT && !PRIMARY && __ballot(state == ST_READY)) c_wt++;
-    if (state == (PRIMARY ? ST_PRIMARY : ST_READY)) {
-      if (!PRIMARY) { RT_PROF_BEGIN(1); }
-      RT_PROF_BEGIN_IF(PRIMARY, 5);
-      iters++;
-      float closest = RT_RAY_TMAX;
-      int hit = -1;
-      // ---- per-ray terms of the phase-1 filter ("phase-1 filter") ----
-      // exact discriminant D = hb^2 - a (|o - c|^2 - r^2), hb = o.d - c.d. With the margin
-      // M = m a (|o|^2 + |c|^2 + r^2), m = RT_P1_MARGIN:
-      //   D + M = (o.d - c.d)^2 + [(m - 1) a |o|^2] + (2 a o).c - a K',  K' = (|c|^2 - r^2) - m (|c|^2 + r^2)
-      // K' is a per-sphere constant (rt_set_scene), everything else per-ray: 8 FMAs per sphere. The
-      // computed value and the oracle's literal discriminant each stay within 51 resp. 54 units of
-      // 2^-24 a (|o|^2 + |c|^2 + r^2) of D while all magnitudes are `tame` (no overflow / underflow);
-      // m = 2^-16 = 256 such units, so a negative sign here is a certain miss of the literal code too.
-      // Rays or scenes outside the tame range skip the filter (every sphere is a candidate).
-      const float a_fast = dot_fast(dx, dy, dz, dx, dy, dz);
-      const float oo = dot_fast(ox, oy, oz, ox, oy, oz);
-      const bool tame = a.p1_tame != 0u && a_fast >= 0x1p-20f && a_fast <= 0x1p20f && oo <= 0x1p40f;
-      p1_ray p1q = {};
-      if (!PRIMARY) {
-        const float nod = -dot_fast(ox, oy, oz, dx, dy, dz);
-        const float na = -a_fast;
-        const float nA = (a_fast * oo) * (RT_P1_MARGIN - 1.0f);
-        const float a2 = a_fast + a_fast;
-        p1q = p1_ray{f32x2{dx, dy}, f32x2{dz, nod}, f32x2{na, nA}, f32x2{a2 * ox, a2 * oy}, f32x2{a2 * oz, 0.0f}};
-      }
-      float a_lit = a_fast, inv_a = 0.0f;
-      rn_divisor a_div = {1.0f, 1.0f, false};
-      if (STRICT) {
-        const float len = sqrt_rn(dot_strict(dx, dy, dz, dx, dy, dz));
-        a_lit = len * len;  // length_squared (wgsl:306-309)
-        a_div = make_divisor(a_lit);
-      } else {
-        inv_a = __builtin_amdgcn_rcpf(a_fast);
-      }
-      // STRICT roots (-hb -+ sq) / a_lit of a tame ray: |hb|, sq < 2^32 and a_lit in [2^-21, 2^21], so the numerator
-      // is below div_core's upper limit, and a numerator under its lower limit 2^-60 gives |quotient| < 2^-38 both
-      // exactly and from div_core - far below RT_RAY_TMIN, where only the comparison `root <= tmin` is used.
-      // Untamed rays take the compiler's division.
-      const unsigned long long any_untame = __ballot(!tame);
-      const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
-      if (COUNT) { c_R++; c_T += n_spheres; }
-      if (!PRIMARY) { RT_PROF_END(1); }
-      for (uint32_t base = 0; base < (PRIMARY ? 1u : n_spheres); base += 32u) {
-        const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
-        // ---- phase 1: sign of D + M for spheres base..base+cnt-1 -> bitmask ----
-        // bit (cnt_pad-1-j) of `missbits` = sign of sphere (base+j)'s value (1 = certain miss)
-        const uint32_t cnt_pad = (cnt + 3u) & ~3u;
-        uint32_t cand;
-        if (PRIMARY) {
-          cand = tmask;  // same bit layout; rt_tile_masks_kernel sets no bit outside `valid`
-        } else {
-          RT_PROF_BEGIN(2);
-          const uint32_t missbits = phase1_missbits<CULL>(sph_p1, base, cnt_pad, p1q);
-#if RT_PROFILE_SECTIONS
-          asm volatile("" :: "v"(missbits));  // keep the loop inside the timed region
-#endif
-          RT_PROF_END(2);
-          // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
-          // (untamed rays take every sphere; the lowest cnt_pad - cnt bits are padding spheres)
-          const uint32_t valid = (cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u);  // wave-uniform
-          cand = (~missbits | untame_fill) & valid;
-        }
-        if (!PRIMARY) { RT_PROF_BEGIN(3); }
-        while (cand) {
-#if RT_PROFILE_SECTIONS
-          if (!PRIMARY) { prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true)); }
-#endif
-          const uint32_t lz = (uint32_t)__builtin_clz(cand);
-          cand &= ~(0x80000000u >> lz);
-          const uint32_t i = base + cnt_pad - 32u + lz;
-          const f32x4 s = SMALL ? sph_lds[i] : a.sph_test[i];
-          const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
-          if (STRICT) {
-            // hit_sphere (wgsl:200-231), literal
-            const float hb = dot_strict(ocx, ocy, ocz, dx, dy, dz);
-            const float len = sqrt_rn(dot_strict(ocx, ocy, ocz, ocx, ocy, ocz));
-            const float c = len * len - s.w;
-            const float disc = hb * hb - a_lit * c;
-            if (!(disc < 0.0f)) {
-              if (COUNT) c_D++;
-              const float sq = sqrt_rn(disc);
-              float root = div_known(-hb - sq, a_div, !tame, any_untame);
-              bool ok = true;
-              if (root <= RT_RAY_TMIN || closest <= root) {
-                root = div_known(-hb + sq, a_div, !tame, any_untame);
-                if (root <= RT_RAY_TMIN || closest <= root) ok = false;
-              }
-              if (ok) { closest = root; hit = (int)i; }
-            }
-          } else {
-            const float hb = dot_fast(ocx, ocy, ocz, dx, dy, dz);
-            const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
-            const float disc = __builtin_fmaf(-a_fast, cc, hb * hb);
-            if (!(disc < 0.0f)) {  // the filter's margin lets a few near misses through
-              if (COUNT) c_D++;
-              const float sq = __builtin_amdgcn_sqrtf(disc);
-              const float r0 = (-hb - sq) * inv_a, r1 = (-hb + sq) * inv_a;
-              const bool ok0 = r0 > RT_RAY_TMIN && r0 < closest;
-              const float root = ok0 ? r0 : r1;
-              if (root > RT_RAY_TMIN && root < closest) { closest = root; hit = (int)i; }
-            }
-          }
-        }
-        if (!PRIMARY) { RT_PROF_END(3); }
-      }
+  const uint32_t n_pad32 = (n_spheres + 3u) & ~3u;  // SPLIT (<= 32 spheres): the one block of the candidate walk
+  // ---- the pieces of trace (wgsl:182-231) and of miss / scatter (wgsl:144-172); the two loop shapes below compose them ----
+  // Per-ray values that outlive the piece that computes them (in the SPLIT shape: across the loop's back edge)
+  float a_lit = 1.0f, a_rcp = 1.0f;  // STRICT: length_squared(dir) (wgsl:306-309) and its refined reciprocal; FAST: |d|^2 and v_rcp of it
+  bool tame = true;                  // the ray is inside the magnitude range of the phase-1 bound and of div_core
+  uint32_t cand = 0;                 // spheres still to be tested exactly, in the bit layout of phase1_missbits
+  uint32_t own = 0;                  // SPLIT: the sphere whose surface the current bounce ray starts on (its last hit)
 
-      if (!PRIMARY) { RT_PROF_BEGIN(4); }
-      if (hit < 0) {
-        // miss (wgsl:144-148); ray_color: color += miss * reflectance; break
-        if (COUNT) c_M++;
-        if (!checker) {
-          const float t = 0.5f * (1.0f - dy);
-          const float it = 1.0f - t;
-          colx = colx + (it + t * 0.5f) * refl;
-          coly = coly + (it + t * 0.7f) * refl;
-          colz = colz + (it + t * 1.0f) * refl;
-        } else {
-          colx = colx + 0.0f * refl; coly = coly + 0.0f * refl; colz = colz + 0.0f * refl;
-        }
-        state = ST_PATH_DONE;
-      } else {
-        if (COUNT) { c_H++; c_S++; }
-        const f32x4 sg = SMALL ? sph_lds[RT_SMALL_MAX + (uint32_t)hit] : a.sph_shade[hit];      // {cx, cy, cz, r}
-        const f32x4 sc = SMALL ? sph_lds[2u * RT_SMALL_MAX + (uint32_t)hit] : a.sph_col[hit];   // {material r, g, b, +-1/r}
-        // hit record of the closest sphere (wgsl:225-227): point = ray_at(t), normal = (point - c) / r
-        float px, py, pz, nx, ny, nz;
-        if (STRICT) {
-          px = ox + closest * dx; py = oy + closest * dy; pz = oz + closest * dz;
-          const float ex = px - sg.x, ey = py - sg.y, ez = pz - sg.z;
-          if (sc.w > 0.0f) {
-            // r is a power of two (rt_set_scene marks that with a positive 1/r): x / r == x * (1/r)
-            // exactly, barring overflow/underflow of a unit-length normal's components
-            nx = ex * sc.w; ny = ey * sc.w; nz = ez * sc.w;
-          } else {
-            const rn_divisor rd = make_divisor(sg.w);
-            div3_rn(ex, ey, ez, rd, nx, ny, nz);
-          }
-        } else {
-          px = __builtin_fmaf(closest, dx, ox); py = __builtin_fmaf(closest, dy, oy); pz = __builtin_fmaf(closest, dz, oz);
-          const float ir = __builtin_fabsf(sc.w);
-          nx = (px - sg.x) * ir; ny = (py - sg.y) * ir; nz = (pz - sg.z) * ir;
-        }
-        // scatter (wgsl:150-168)
-        float kk = (1.0f - RT_LOCAL_REFLECTANCE) * refl;
-        if (checker) {
-          const float fx = __builtin_floorf(4.0f * nx);
-          const float fy = __builtin_floorf(4.0f * ny + 0.5f);
-          const float h = (fx + fy) * 0.5f;
-          kk = (h == __builtin_floorf(h)) ? refl : 0.0f;
-        }
-        colx = colx + sc.x * kk; coly = coly + sc.y * kk; colz = colz + sc.z * kk;
-        refl = refl * RT_LOCAL_REFLECTANCE;
-        ox = px; oy = py; oz = pz;
-        depth++;
-        if ((hit & 1) == 0) {
-          // reflection (wgsl:170-172): dir - 2*dot(dir, n)*n
-          if (COUNT) c_Sm++;
-          if (STRICT) {
-            const float k2 = 2.0f * dot_strict(dx, dy, dz, nx, ny, nz);
-            dx = dx - k2 * nx; dy = dy - k2 * ny; dz = dz - k2 * nz;
-          } else {
-            const float k2 = -2.0f * dot_fast(dx, dy, dz, nx, ny, nz);
-            dx = __builtin_fmaf(k2, nx, dx); dy = __builtin_fmaf(k2, ny, dy); dz = __builtin_fmaf(k2, nz, dz);
-          }
-          state = depth > (uint32_t)RT_MAX_RAY_DEPTH ? ST_PATH_DONE : ST_READY;
-        } else {
-          // normal + random_unit_vector(): the direction is drawn in [G]; park the normal in d
-          if (COUNT) c_Sd++;
-          dx = nx; dy = ny; dz = nz;
-          state = ST_NEED_DIR;
-        }
-      }
-      if (!PRIMARY) { RT_PROF_END(4); }
-      RT_PROF_END_IF(PRIMARY, 5);
+  // OWN-SPHERE DROP (SPLIT shape). A bounce ray starts ON the sphere it just hit, so phase 1 can never exclude that
+  // sphere (its discriminant is ~ hb^2 >= 0) - and the exact test then rejects both roots almost always: they are ~ 0.
+  // This proves the rejection from two dot products. Literal test of sphere `own` for the ray (o, d), wgsl:207-223:
+  //   oc = o - c (the three subtractions below ARE the literal ones), hb = dot(oc, d), x = dot(oc, oc),
+  //   c_l = fl(fl(sqrt(x))^2) - fl(r r), disc = fl(hb^2) - fl(a c_l), roots (-hb -+ sqrt(disc)) / a.
+  // Let hb >= 2^-30 (so hb^2 neither under- nor overflows; a, |o|, the scene are `tame`).
+  //  * c_l >= 0: fl(a c_l) >= 0, so disc <= fl(hb^2) and sqrt_rn(disc) <= sqrt_rn(fl(hb^2)) = hb (radix 2, no
+  //    underflow): -hb + sq <= 0, both roots <= 0 <= tmin: rejected (or disc < 0: rejected at once).
+  //  * c_l < 0, delta = -c_l: fl(len^2) >= x (1 - 2^-24)^3, hence delta <= (rr - x + 3.01 u x)(1 + u), u = 2^-24, and
+  //    delta <= dub (1 + 4u) for dub = fl(fl(rr - x) + 2^-20 x) below. sq <= sqrt(hb^2 + a delta)(1 + u)^2
+  //    <= (hb + a delta / (2 hb))(1 + u)^2, so root2 = fl(fl(-hb + sq) / a) <= [delta / (2 hb) + 2.1 u hb / a](1 + 6u).
+  //    With dub <= 2^-11 hb and hb <= 2048 a that is <= (2.45e-4 + 2.57e-4)(1 + 6u) < tmin = 1e-3: rejected; root1 < 0.
+  // So under `drop` hit_sphere returns false for `own` in the literal arithmetic (it has no side effect then), and the
+  // sphere leaves the candidate set. Grazing departures (hb tiny) and rays from huge spheres keep their exact test.
+  auto own_sphere_bit = [&]() __attribute__((always_inline)) -> uint32_t {
+    const f32x4 so = sph_lds[own];  // {c, fl(r r)}
+    const float ex = ox - so.x, ey = oy - so.y, ez = oz - so.z;
+    const float x = STRICT ? dot_strict(ex, ey, ez, ex, ey, ez) : dot_fast(ex, ey, ez, ex, ey, ez);
+    const float hbo = STRICT ? dot_strict(ex, ey, ez, dx, dy, dz) : dot_fast(ex, ey, ez, dx, dy, dz);
+    const float dub = __builtin_fmaf(x, 0x1p-20f, so.w - x);
+    const bool drop = tame && hbo >= 0x1p-30f && dub <= 0x1p-11f * hbo && hbo <= 2048.0f * a_lit;
+    return drop ? 1u << (n_pad32 - 1u - own) : 0u;
+  };
+
+  // [P] per-ray prelude; FILTER: also the per-ray terms of the phase-1 filter ("phase-1 filter"):
+  // exact discriminant D = hb^2 - a (|o - c|^2 - r^2), hb = o.d - c.d. With the margin
+  // M = m a (|o|^2 + |c|^2 + r^2), m = RT_P1_MARGIN:
+  //   D + M = (o.d - c.d)^2 + [(m - 1) a |o|^2] + (2 a o).c - a K',  K' = (|c|^2 - r^2) - m (|c|^2 + r^2)
+  // K' is a per-sphere constant (rt_set_scene), everything else per-ray: 8 FMAs per sphere. The
+  // computed value and the oracle's literal discriminant each stay within 51 resp. 54 units of
+  // 2^-24 a (|o|^2 + |c|^2 + r^2) of D while all magnitudes are `tame` (no overflow / underflow);
+  // m = 2^-16 = 256 such units, so a negative sign here is a certain miss of the literal code too.
+  // Rays or scenes outside the tame range skip the filter (every sphere is a candidate).
+  auto ray_prelude = [&](auto filter_tag, p1_ray& p1q) __attribute__((always_inline)) {
+    constexpr bool FILTER = decltype(filter_tag)::value;
+    const float a_fast = dot_fast(dx, dy, dz, dx, dy, dz);
+    const float oo = dot_fast(ox, oy, oz, ox, oy, oz);
+    tame = a.p1_tame != 0u && a_fast >= 0x1p-20f && a_fast <= 0x1p20f && oo <= 0x1p40f;
+    if (FILTER) {
+      const float nod = -dot_fast(ox, oy, oz, dx, dy, dz);
+      const float na = -a_fast;
+      const float nA = (a_fast * oo) * (RT_P1_MARGIN - 1.0f);
+      const float a2 = a_fast + a_fast;
+      p1q = p1_ray{f32x2{dx, dy}, f32x2{dz, nod}, f32x2{na, nA}, f32x2{a2 * ox, a2 * oy}, f32x2{a2 * oz, 0.0f}};
+    }
+    if (STRICT) {
+      const float len = sqrt_rn(dot_strict(dx, dy, dz, dx, dy, dz));
+      a_lit = len * len;  // length_squared (wgsl:306-309)
+      a_rcp = make_divisor(a_lit).r;
+    } else {
+      a_lit = a_fast;
+      a_rcp = __builtin_amdgcn_rcpf(a_fast);
     }
   };
+
+  // [W] hit_sphere (wgsl:200-231) for the lane's candidates among spheres base .., in ascending sphere order.
+  // STRICT roots (-hb -+ sq) / a_lit of a tame ray: |hb|, sq < 2^32 and a_lit in [2^-21, 2^21], so the numerator
+  // is below div_core's upper limit, and a numerator under its lower limit 2^-60 gives |quotient| < 2^-38 both
+  // exactly and from div_core - far below RT_RAY_TMIN, where only the comparison `root <= tmin` is used.
+  // Untamed rays take the compiler's division.
+  auto walk = [&](uint32_t base, uint32_t cnt_pad, float& closest, int& hit, unsigned long long any_untame) __attribute__((always_inline)) {
+    const rn_divisor a_div = {a_lit, a_rcp, false};
+    while (cand) {
+#if RT_PROFILE_SECTIONS
+      prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true));
+#endif
+      const uint32_t lz = (uint32_t)__builtin_clz(cand);
+      cand &= ~(0x80000000u >> lz);
+      const uint32_t i = base + cnt_pad - 32u + lz;
+      const f32x4 s = SMALL ? sph_lds[i] : a.sph_test[i];
+      const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
+      if (STRICT) {
+        // hit_sphere (wgsl:200-231), literal
+        const float hb = dot_strict(ocx, ocy, ocz, dx, dy, dz);
+        const float len = sqrt_rn(dot_strict(ocx, ocy, ocz, ocx, ocy, ocz));
+        const float c = len * len - s.w;
+        const float disc = hb * hb - a_lit * c;
+        if (!(disc < 0.0f)) {
+          if (COUNT) c_D++;
+          const float sq = sqrt_rn(disc);
+          float root = div_known(-hb - sq, a_div, !tame, any_untame);
+          bool ok = true;
+          if (root <= RT_RAY_TMIN || closest <= root) {
+            root = div_known(-hb + sq, a_div, !tame, any_untame);
+            if (root <= RT_RAY_TMIN || closest <= root) ok = false;
+          }
+          if (ok) { closest = root; hit = (int)i; }
+        }
+      } else {
+        const float hb = dot_fast(ocx, ocy, ocz, dx, dy, dz);
+        const float cc = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
+        const float disc = __builtin_fmaf(-a_lit, cc, hb * hb);
+        if (!(disc < 0.0f)) {  // the filter's margin lets a few near misses through
+          if (COUNT) c_D++;
+          const float sq = __builtin_amdgcn_sqrtf(disc);
+          const float r0 = (-hb - sq) * a_rcp, r1 = (-hb + sq) * a_rcp;
+          const bool ok0 = r0 > RT_RAY_TMIN && r0 < closest;
+          const float root = ok0 ? r0 : r1;
+          if (root > RT_RAY_TMIN && root < closest) { closest = root; hit = (int)i; }
+        }
+      }
+    }
+  };
+
+  // [M] miss (wgsl:144-148); ray_color: color += miss * reflectance; break
+  auto shade_miss = [&]() __attribute__((always_inline)) {
+    if (COUNT) c_M++;
+    if (!checker) {
+      const float t = 0.5f * (1.0f - dy);
+      const float it = 1.0f - t;
+      colx = colx + (it + t * 0.5f) * refl;
+      coly = coly + (it + t * 0.7f) * refl;
+      colz = colz + (it + t * 1.0f) * refl;
+    } else {
+      colx = colx + 0.0f * refl; coly = coly + 0.0f * refl; colz = colz + 0.0f * refl;
+    }
+    state = ST_PATH_DONE;
+  };
+
+  // [S] hit record of the closest sphere (wgsl:225-227) + scatter (wgsl:150-172)
+  auto shade_hit = [&](float closest, int hit) __attribute__((always_inline)) {
+    if (COUNT) { c_H++; c_S++; }
+    const f32x4 sg = SMALL ? sph_lds[RT_SMALL_MAX + (uint32_t)hit] : a.sph_shade[hit];      // {cx, cy, cz, r}
+    const f32x4 sc = SMALL ? sph_lds[2u * RT_SMALL_MAX + (uint32_t)hit] : a.sph_col[hit];   // {material r, g, b, +-1/r}
+    // point = ray_at(t), normal = (point - c) / r
+    float px, py, pz, nx, ny, nz;
+    if (STRICT) {
+      px = ox + closest * dx; py = oy + closest * dy; pz = oz + closest * dz;
+      const float ex = px - sg.x, ey = py - sg.y, ez = pz - sg.z;
+      if (sc.w > 0.0f) {
+        // r is a power of two (rt_set_scene marks that with a positive 1/r): x / r == x * (1/r)
+        // exactly, barring overflow/underflow of a unit-length normal's components
+        nx = ex * sc.w; ny = ey * sc.w; nz = ez * sc.w;
+      } else {
+        const rn_divisor rd = make_divisor(sg.w);
+        div3_rn(ex, ey, ez, rd, nx, ny, nz);
+      }
+    } else {
+      px = __builtin_fmaf(closest, dx, ox); py = __builtin_fmaf(closest, dy, oy); pz = __builtin_fmaf(closest, dz, oz);
+      const float ir = __builtin_fabsf(sc.w);
+      nx = (px - sg.x) * ir; ny = (py - sg.y) * ir; nz = (pz - sg.z) * ir;
+    }
+    // scatter (wgsl:150-168)
+    float kk = (1.0f - RT_LOCAL_REFLECTANCE) * refl;
+    if (checker) {
+      const float fx = __builtin_floorf(4.0f * nx);
+      const float fy = __builtin_floorf(4.0f * ny + 0.5f);
+      const float h = (fx + fy) * 0.5f;
+      kk = (h == __builtin_floorf(h)) ? refl : 0.0f;
+    }
+    colx = colx + sc.x * kk; coly = coly + sc.y * kk; colz = colz + sc.z * kk;
+    refl = refl * RT_LOCAL_REFLECTANCE;
+    ox = px; oy = py; oz = pz;
+    if (SPLIT) own = (uint32_t)hit;
+    depth++;
+    if ((hit & 1) == 0) {
+      // reflection (wgsl:170-172): dir - 2*dot(dir, n)*n
+      if (COUNT) c_Sm++;
+      if (STRICT) {
+        const float k2 = 2.0f * dot_strict(dx, dy, dz, nx, ny, nz);
+        dx = dx - k2 * nx; dy = dy - k2 * ny; dz = dz - k2 * nz;
+      } else {
+        const float k2 = -2.0f * dot_fast(dx, dy, dz, nx, ny, nz);
+        dx = __builtin_fmaf(k2, nx, dx); dy = __builtin_fmaf(k2, ny, dy); dz = __builtin_fmaf(k2, nz, dz);
+      }
+      state = depth > (uint32_t)RT_MAX_RAY_DEPTH ? ST_PATH_DONE : ST_READY;
+    } else {
+      // normal + random_unit_vector(): the direction is drawn in [G]; park the normal in d
+      if (COUNT) c_Sd++;
+      dx = nx; dy = ny; dz = nz;
+      state = ST_NEED_DIR;
+    }
+  };
+
+  // one rejection round of random_in_unit_sphere (wgsl:281-290) for the lanes in NEED_DIR
+  // STRICT: accept iff fl(fl(sqrt(l2))^2) < 1 (wgsl:284,306-309). fl(sqrt(.)) is monotone with
+  // fl(sqrt(1)) = 1, and for l2 <= 1 - 2^-24 the rounded root is <= 1 - 2^-24, whose square
+  // rounds below 1: the test equals l2 < 1 exactly.
+  auto try_direction = [&](uint32_t s0, uint32_t s1, uint32_t s2) __attribute__((always_inline)) {
+    if (COUNT) c_J++;
+    const float qx = rng_signed(s0), qy = rng_signed(s1), qz = rng_signed(s2);  // rand() * 2 - 1
+    const float l2 = STRICT ? dot_strict(qx, qy, qz, qx, qy, qz) : dot_fast(qx, qy, qz, qx, qy, qz);
+    gqx = qx; gqy = qy; gqz = qz; gl2 = l2;  // a rejected point is dead: no select needed
+    if (l2 < 1.0f) state = ST_GOT_DIR;
+  };
+  // get_random_ray (wgsl:174-180) from the two jitter draws; ray_color's start values (wgsl:126-130)
+  auto start_ray = [&](uint32_t s0, uint32_t s1) __attribute__((always_inline)) {
+    const float px = rng_jitter(s0), py = rng_jitter(s1);
+    dx = pcx + px * pdx; dy = pcy + py * pdy; dz = pcz + 1.0f * pdz;
+    ox = a.pos[0]; oy = a.pos[1]; oz = a.pos[2];
+    colx = coly = colz = 0.0f; refl = 1.0f; depth = 0;
+    if (COUNT) c_N++;
+  };
+  // rec.normal + normalize(p) (wgsl:165,292-294), once per accepted lane after all rounds
+  auto finish_direction = [&]() __attribute__((always_inline)) {
+    if (STRICT) {
+      // the components of an accepted point are 0 or multiples of 2^-22 in (-1, 1) and |p| >= 2^-22 unless p = 0:
+      // all inside div_core's range (a +0 component gives +0 like the IEEE quotient); p = 0 (0/0) goes the generic way
+      const rn_divisor len = make_divisor(sqrt_rn(gl2));
+      const bool zero_len = !(gl2 >= 0x1p-50f);
+      const unsigned long long any_zero_len = __ballot(zero_len);
+      const float ux = div_known(gqx, len, zero_len, any_zero_len), uy = div_known(gqy, len, zero_len, any_zero_len),
+                  uz = div_known(gqz, len, zero_len, any_zero_len);
+      dx = dx + ux; dy = dy + uy; dz = dz + uz;
+    } else {
+      const float il = __builtin_amdgcn_rsqf(gl2);
+      dx = __builtin_fmaf(gqx, il, dx); dy = __builtin_fmaf(gqy, il, dy); dz = __builtin_fmaf(gqz, il, dz);
+    }
+    state = depth > (uint32_t)RT_MAX_RAY_DEPTH ? ST_PATH_DONE : ST_READY;  // for (depth = 0; depth <= MAX_RAY_DEPTH; depth++) (wgsl:131)
+  };
+  const uint32_t valid32 = (n_pad32 >= 32u ? 0xffffffffu : (1u << n_pad32) - 1u) & ~((1u << (n_pad32 - (n_spheres < 32u ? n_spheres : 32u) & 31u)) - 1u);
 
   for (;;) {
 #if RT_PROFILE_SECTIONS
@@ -802,95 +838,134 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     }  // parked
 
     // ================= [G] random draws, [C] trace + shade =================
-    // Two loop shapes. The classic one (one trace per iteration): round 0 of the draws is shared - lanes starting a
-    // sample draw the two jitter numbers of get_random_ray (wgsl:174-180) with the same instructions that give lanes
-    // in random_in_unit_sphere (wgsl:281-290) the first two of their three numbers - then further rounds for NEED_DIR,
-    // then ONE trace for every lane that has a ray.
-    // The SPLIT one (scenes of <= 32 spheres with per-tile candidate masks, DESIGN.md "primary / bounce split"): a lane
-    // can trace its PRIMARY ray and, when that hits, its first BOUNCE ray in the same iteration:
-    //   [G0] NEW_RAY lanes draw the jitter -> [C-A] primary trace: candidates are the tile's mask, no phase 1, no
-    //   filter terms -> shade -> [G1] rejection rounds for every lane that needs a direction (from [C-A] just now or
-    //   from [C-B] of the previous iteration) -> [C-B] the general trace (phase 1 + phase 2) -> shade.
-    // Rays per lane and iteration rise from 0.92 to ~1.6 on the 20-sphere scene, the rounds and the bookkeeping
-    // sections are paid once per iteration as before, and primary rays (43 % of the rays there) skip phase 1.
-    RT_PROF_BEGIN(0);
     if (!SPLIT) {
-    if (state == ST_NEW_RAY || state == ST_NEED_DIR) {
-      uint32_t s0, s1;
-      RT_STEP(s0); RT_STEP(s1);
-      if (state == ST_NEW_RAY) {
-        const float px = rng_jitter(s0), py = rng_jitter(s1);
-        dx = pcx + px * pdx; dy = pcy + py * pdy; dz = pcz + 1.0f * pdz;
-        ox = a.pos[0]; oy = a.pos[1]; oz = a.pos[2];
-        colx = coly = colz = 0.0f; refl = 1.0f; depth = 0;
-        if (COUNT) c_N++;
-        state = ST_READY;
-      } else {
-        uint32_t s2;
-        RT_STEP(s2);
-        if (COUNT) c_J++;
-        const float qx = rng_signed(s0), qy = rng_signed(s1), qz = rng_signed(s2);  // rand() * 2 - 1
-        const float l2 = STRICT ? dot_strict(qx, qy, qz, qx, qy, qz) : dot_fast(qx, qy, qz, qx, qy, qz);
-        // STRICT: accept iff fl(fl(sqrt(l2))^2) < 1 (wgsl:284,306-309). fl(sqrt(.)) is monotone with
-        // fl(sqrt(1)) = 1, and for l2 <= 1 - 2^-24 the rounded root is <= 1 - 2^-24, whose square
-        // rounds below 1: the test equals l2 < 1 exactly.
-        gqx = qx; gqy = qy; gqz = qz; gl2 = l2;  // a rejected point is dead: no select needed
-        if (l2 < 1.0f) state = ST_GOT_DIR;
-      }
-    }
-    if (COUNT) c_wr++;
-    } else {
-      // [G0] get_random_ray (wgsl:174-180) for the lanes that start a sample
-      if (state == ST_NEW_RAY) {
+      // CLASSIC SHAPE, one trace per lane and iteration. Round 0 of the draws is shared: lanes starting a sample draw
+      // the two jitter numbers of get_random_ray (wgsl:174-180) with the same instructions that give lanes in
+      // random_in_unit_sphere (wgsl:281-290) the first two of their three numbers; further rounds serve NEED_DIR only.
+      RT_PROF_BEGIN(0);
+      if (state == ST_NEW_RAY || state == ST_NEED_DIR) {
         uint32_t s0, s1;
         RT_STEP(s0); RT_STEP(s1);
-        const float px = rng_jitter(s0), py = rng_jitter(s1);
-        dx = pcx + px * pdx; dy = pcy + py * pdy; dz = pcz + 1.0f * pdz;
-        ox = a.pos[0]; oy = a.pos[1]; oz = a.pos[2];
-        colx = coly = colz = 0.0f; refl = 1.0f; depth = 0;
-        state = ST_PRIMARY;
+        if (state == ST_NEW_RAY) {
+          start_ray(s0, s1);
+          state = ST_READY;
+        } else {
+          uint32_t s2;
+          RT_STEP(s2);
+          try_direction(s0, s1, s2);
+        }
       }
-      RT_PROF_END(0);
-      // [C-A] primary rays: the tile's candidate mask instead of phase 1
-      trace_and_shade(std::integral_constant<bool, true>{});
-      RT_PROF_BEGIN(0);
-    }
+      if (COUNT) c_wr++;
 #ifndef RT_ROUND_MIN_LANES
 #define RT_ROUND_MIN_LANES 1u  // a further round runs while at least this many lanes still need a direction
 #endif
-    for (uint32_t round = SPLIT ? 0u : 1u; round < a.reject_tries && (uint32_t)__popcll(__ballot(state == ST_NEED_DIR)) >= RT_ROUND_MIN_LANES; ++round) {
-      if (COUNT) c_wr++;
-      if (state == ST_NEED_DIR) {
-        uint32_t s0, s1, s2;
-        RT_STEP(s0); RT_STEP(s1); RT_STEP(s2);
-        if (COUNT) c_J++;
-        const float qx = rng_signed(s0), qy = rng_signed(s1), qz = rng_signed(s2);
-        const float l2 = STRICT ? dot_strict(qx, qy, qz, qx, qy, qz) : dot_fast(qx, qy, qz, qx, qy, qz);
-        gqx = qx; gqy = qy; gqz = qz; gl2 = l2;
-        if (l2 < 1.0f) state = ST_GOT_DIR;
+      for (uint32_t round = 1; round < a.reject_tries && (uint32_t)__popcll(__ballot(state == ST_NEED_DIR)) >= RT_ROUND_MIN_LANES; ++round) {
+        if (COUNT) c_wr++;
+        if (state == ST_NEED_DIR) {
+          uint32_t s0, s1, s2;
+          RT_STEP(s0); RT_STEP(s1); RT_STEP(s2);
+          try_direction(s0, s1, s2);
+        }
+      }
+      if (state == ST_GOT_DIR) finish_direction();
+      RT_PROF_END(0);
+      // ---- [C] trace + shade (lanes with a ray) ----
+      if (COUNT && __ballot(state == ST_READY)) c_wt++;
+      if (state == ST_READY) {
+        RT_PROF_BEGIN(1);
+        iters++;
+        float closest = RT_RAY_TMAX;
+        int hit = -1;
+        p1_ray p1q;
+        ray_prelude(std::integral_constant<bool, true>{}, p1q);
+        const unsigned long long any_untame = __ballot(!tame);
+        const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
+        if (COUNT) { c_R++; c_T += n_spheres; }
+        RT_PROF_END(1);
+        for (uint32_t base = 0; base < n_spheres; base += 32u) {
+          const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
+          // ---- phase 1: sign of D + M for spheres base..base+cnt-1 -> bitmask ----
+          // bit (cnt_pad-1-j) of `missbits` = sign of sphere (base+j)'s value (1 = certain miss)
+          const uint32_t cnt_pad = (cnt + 3u) & ~3u;
+          RT_PROF_BEGIN(2);
+          const uint32_t missbits = phase1_missbits<CULL>(sph_p1, base, cnt_pad, p1q);
+#if RT_PROFILE_SECTIONS
+          asm volatile("" :: "v"(missbits));  // keep the loop inside the timed region
+#endif
+          RT_PROF_END(2);
+          RT_PROF_BEGIN(3);
+          // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
+          // (untamed rays take every sphere; the lowest cnt_pad - cnt bits are padding spheres)
+          const uint32_t valid = (cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u);  // wave-uniform
+          cand = (~missbits | untame_fill) & valid;
+          walk(base, cnt_pad, closest, hit, any_untame);
+          RT_PROF_END(3);
+        }
+        RT_PROF_BEGIN(4);
+        if (hit < 0) shade_miss(); else shade_hit(closest, hit);
+        RT_PROF_END(4);
+      }
+    } else {
+      // SPLIT SHAPE (scenes of <= 32 spheres whose launch has per-tile candidate masks; DESIGN.md, "primary / bounce
+      // split"). Every section appears once, and a lane passes through up to two rays per iteration:
+      //   [G0] NEW_RAY: jitter draws, prelude; candidates := the tile's mask (no phase 1: every sphere outside the mask
+      //        is a certain miss of every primary ray of the tile in the literal arithmetic, and hit_sphere has no
+      //        side effect when it returns false)                                              -> ST_TEST
+      //   [W]  ST_TEST: exact tests of the candidates - of a fresh primary ray, or of the bounce ray whose phase 1 ran
+      //        at the end of the previous iteration - then miss or scatter                  -> PATH_DONE | READY | NEED_DIR
+      //   [G1] NEED_DIR: rejection rounds, normalize                                           -> READY
+      //   [P1] READY: prelude + phase 1 over all spheres; no candidate = miss, at once         -> PATH_DONE | ST_TEST
+      // 93 % of the primary rays of the 20-sphere scene's traced tiles hit and 71 % of its bounce rays have no
+      // candidate, so the common path "primary hit, bounce miss" is ONE iteration (the classic shape needs two), and
+      // the rounds, the walk and the scatter are each paid once per iteration for primary and bounce lanes together.
+      RT_PROF_BEGIN(0);
+      if (state == ST_NEW_RAY) {
+        uint32_t s0, s1;
+        RT_STEP(s0); RT_STEP(s1);
+        start_ray(s0, s1);
+        p1_ray unused;
+        iters++;
+        ray_prelude(std::integral_constant<bool, false>{}, unused);
+        cand = tmask;
+        state = ST_TEST;
+      }
+      RT_PROF_END(0);
+      RT_PROF_BEGIN(3);
+      if (state == ST_TEST) {
+        float closest = RT_RAY_TMAX;
+        int hit = -1;
+        walk(0u, n_pad32, closest, hit, __ballot(!tame));
+        RT_PROF_END(3);
+        RT_PROF_BEGIN(4);
+        if (hit < 0) shade_miss(); else shade_hit(closest, hit);
+        RT_PROF_END(4);
+        RT_PROF_BEGIN(3);
+      }
+      RT_PROF_END(3);
+      RT_PROF_BEGIN(0);
+      for (uint32_t round = 0; round < a.reject_tries && __ballot(state == ST_NEED_DIR) != 0ull; ++round) {
+        if (state == ST_NEED_DIR) {
+          uint32_t s0, s1, s2;
+          RT_STEP(s0); RT_STEP(s1); RT_STEP(s2);
+          try_direction(s0, s1, s2);
+        }
+      }
+      if (state == ST_GOT_DIR) finish_direction();
+      RT_PROF_END(0);
+      if (state == ST_READY) {
+        RT_PROF_BEGIN(1);
+        iters++;
+        p1_ray p1q;
+        ray_prelude(std::integral_constant<bool, true>{}, p1q);
+        RT_PROF_END(1);
+        RT_PROF_BEGIN(2);
+        const uint32_t missbits = phase1_missbits<CULL>(sph_p1, 0u, n_pad32, p1q);
+        cand = (~missbits | (tame ? 0u : 0xffffffffu)) & valid32 & ~own_sphere_bit();
+        state = ST_TEST;
+        if (cand == 0u) shade_miss();
+        RT_PROF_END(2);
       }
     }
-    if (state == ST_GOT_DIR) {
-      // rec.normal + normalize(p) (wgsl:165,292-294), once per accepted lane after all rounds
-      if (STRICT) {
-        // the components of an accepted point are 0 or multiples of 2^-22 in (-1, 1) and |p| >= 2^-22 unless p = 0:
-        // all inside div_core's range (a +0 component gives +0 like the IEEE quotient); p = 0 (0/0) goes the generic way
-        const rn_divisor len = make_divisor(sqrt_rn(gl2));
-        const bool zero_len = !(gl2 >= 0x1p-50f);
-        const unsigned long long any_zero_len = __ballot(zero_len);
-        const float ux = div_known(gqx, len, zero_len, any_zero_len), uy = div_known(gqy, len, zero_len, any_zero_len),
-                    uz = div_known(gqz, len, zero_len, any_zero_len);
-        dx = dx + ux; dy = dy + uy; dz = dz + uz;
-      } else {
-        const float il = __builtin_amdgcn_rsqf(gl2);
-        dx = __builtin_fmaf(gqx, il, dx); dy = __builtin_fmaf(gqy, il, dy); dz = __builtin_fmaf(gqz, il, dz);
-      }
-      state = depth > (uint32_t)RT_MAX_RAY_DEPTH ? ST_PATH_DONE : ST_READY;  // for (depth = 0; depth <= MAX_RAY_DEPTH; depth++) (wgsl:131)
-    }
-
-    RT_PROF_END(0);
-    // ================= [C] / [C-B] trace + shade (lanes with a ray) =================
-    trace_and_shade(std::integral_constant<bool, false>{});
   }
 
   const rt_kargs_cptr ca = cold_args();
@@ -906,8 +981,8 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     atomicMax(&ca->counters[9], prof_rstart + rlife);
     atomicAdd(&ca->counters[10], prof_rstart & 0xffffffffull);
     atomicAdd(&ca->counters[11], (prof_rstart + rlife) & 0xffffffffull);
-    atomicAdd(&ca->counters[12], SPLIT ? prof_acc5 : prof_p2_lanes);  // SPLIT: cycles in [C-A]; else phase-2 loop: lane-iterations
-    atomicAdd(&ca->counters[13], prof_p2_waves);  // phase-2 loop ([C-B]): wave-iterations
+    atomicAdd(&ca->counters[12], prof_p2_lanes);  // candidate walk: lane-iterations
+    atomicAdd(&ca->counters[13], prof_p2_waves);  // candidate walk: wave-iterations
   }
 #endif
   if (COUNT) {

@@ -28,19 +28,13 @@ def run(name, W, H, spp, scene, shade, math):
     span = (c["N"] - t0) * 1e-5
     occ = rt.occupancy()
     p2_lanes, p2_waves = occ["slots_trace"], occ["slots_reject"]
-    split = os.environ.get("RT_SPLIT", "1") != "0" and sp.shape[0] <= 32  # SPLIT variants report the cycles of [C-A] in slot 12
-    if split:
-        parts.append(("[C-A] primary", p2_lanes))
-        other -= p2_lanes
+    split = os.environ.get("RT_SPLIT", "1") != "0" and sp.shape[0] <= 32  # SPLIT loop shape: "phase 2" = the one candidate walk, "shade" = the one scatter
     n = 6144  # 24 waves per CU x 256 CUs
     mean_start = (c["P"] / n - (t0 & 0xffffffff)) * 1e-5
     mean_end = (c["rand_calls"] / n - (t0 & 0xffffffff)) * 1e-5
     print(f"   launch span {span:.2f} ms; mean wave start +{mean_start:.2f} ms, mean wave end +{mean_end:.2f} ms")
-    if split:
-        print(f"   phase-2 loop of [C-B]: {p2_waves / iters:.2f} wave-iterations per loop iteration; rays per lane and iteration: see quick_perf")
-    else:
-        print(f"   phase-2 loop: {p2_waves / iters:.2f} wave-iterations per trace iteration, {p2_lanes / max(p2_waves, 1):.1f} of 64 lanes active, "
-              f"{p2_lanes / iters:.1f} candidates per wave and trace iteration")
+    print(f"   {'SPLIT shape; ' if split else ''}candidate walk: {p2_waves / iters:.2f} wave-iterations per loop iteration, {p2_lanes / max(p2_waves, 1):.1f} of 64 lanes active, "
+          f"{p2_lanes / iters:.1f} candidates per wave and loop iteration")
     other = life - sum(v for _, v in parts)
     for k, v in parts + [("[E][F][A] + loop", other)]:
         print(f"   {k:18s} {100.0*v/life:5.1f} %   {v/iters:7.0f} cycles/iteration")
