@@ -8,12 +8,15 @@ A STEP is one compute pass (`rt_compute`, reference Raytracer::compute, src/rayt
 over the whole image of the workload BASELINE.json's metric is quoted on: C3 = 3840x2160, 64 spp,
 glowing-checkers scene (random_bunch(20)). rt_compute, like the reference's compute, records the pass;
 the library runs up to 8 recorded passes as one batched launch when the caller synchronises (bit-identical
-to one launch per pass; `per_pass_launches` in the JSON line is the same measurement with RT_DEFER_FRAMES=1). With N GPUs the progressive render is split by disjoint
-per-frame sample sets (BASELINE north_star's second partition): in step i rank r renders frame
-i*N + r of the whole 4K image into a float sum, so per-GPU work is fixed ("weak" scaling) and a step
-of the job is N frames; the per-GPU sums are combined by ONE RCCL sum-reduce at the end of the
-render, inside the timed region. `--split tiles` selects the image-tile partition instead (strong
-scaling on one frame; bit-identical to the 1-GPU image).
+to one launch per pass; `per_pass_launches` in the JSON line is the same measurement with RT_DEFER_FRAMES=1).
+The K timed steps are one render; the render is repeated (each repetition bracketed and timed on its own) until at
+least one second has been measured, and `value` is K steps' samples over the MEAN repetition time (`repeats`).
+With N GPUs the default partition is BASELINE config 3's: image tiles (`--split tiles`: rank r renders the 8x8 tiles
+t = r mod N of every frame, "strong" scaling on the fixed 4K frame, bit-identical to the 1-GPU image), the per-GPU
+images combined by ONE RCCL sum-reduce at the end of the render, inside the timed region. `--split frames` (the
+default for C5, BASELINE config 5) splits the progressive render by disjoint per-frame sample sets instead: in step i
+rank r renders frame i*N + r of the whole image into a float sum, per-GPU work is fixed ("weak" scaling) and a step
+of the job is N frames; the N > 1 line carries the other split's measurement as `other_split`.
 
 Prints ONE JSON line (rank 0). `value` = covered pixels x spp x K / seconds, whole job, inputs
 resident in HBM, RT_MATH_STRICT (the mode that is bit-identical to the oracle). Extra objects:
@@ -52,22 +55,24 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--config", default="C3", help="C2 | C3 | C4 (C3 is the headline: 4K, 64 spp)")
     p.add_argument("--math", default="strict", choices=["strict", "fast"])
-    p.add_argument("--split", default="frames", choices=["tiles", "frames"],
-                   help="N > 1: frames = disjoint frame sets of the whole image per GPU (weak scaling, default); "
-                        "tiles = interleaved 8x8 tiles of one frame (strong scaling)")
+    p.add_argument("--split", default=None, choices=["tiles", "frames"],
+                   help="N > 1: tiles = interleaved 8x8 tiles of every frame (strong scaling; default, BASELINE config 3); "
+                        "frames = disjoint frame sets of the whole image per GPU (weak scaling; default for C5)")
+    p.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step render until this much time is measured")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the fast_math side measurement")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     return p.parse_args()
 
 
-def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, device, use_dist):
-    """Times `steps` compute passes. Returns dict(seconds, kernel_ms, launches, flops_per_launch, samples)."""
+def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, device, use_dist, min_seconds=1.0, max_repeats=64):
+    """Times `steps` compute passes, repeated until `min_seconds` are measured. Returns dict(seconds = mean time of
+    one repetition, repeats, kernel_ms, launches, flops_per_launch, ...)."""
     from raytracer_amd import dist as rdist
     from raytracer_amd import host
 
     W, H, spp = cfg["width"], cfg["height"], cfg["spp"]
-    frames_total = warmup + steps + 4
+    frames_total = warmup + steps * max_repeats + 4
     rt = R.Raytracer(W, H, flags, device=device)
     rt.set_scene(cfg["spheres"], cfg["materials"])
     img = rdist.DeviceImage(rt, f"cuda:{device}") if use_dist else None
@@ -100,19 +105,30 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
     rt.sync()
     rt.enable_timing(True)
     rt.timing_reset()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        step(i)
-    rt.sync()
-    if use_dist:
-        rdist.combine_sum(img.tensor, dst=0)  # ONE RCCL reduce per render
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    seconds = time.perf_counter() - t0
+    total, repeats, at = 0.0, 0, warmup
+    while True:
+        # one repetition = EXACTLY `steps` steps, bracketed by barrier + synchronize on both sides
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(at, at + steps):
+            step(i)
+        rt.sync()
+        if use_dist:
+            rdist.combine_sum(img.tensor, dst=0)  # ONE RCCL reduce per render
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        total += time.perf_counter() - t0
+        repeats += 1
+        at += steps
+        go_on = torch.tensor([1.0 if (total < min_seconds and repeats < max_repeats) else 0.0], device=f"cuda:{device}")
+        if use_dist and world > 1:
+            dist.all_reduce(go_on, op=dist.ReduceOp.MAX)  # every rank runs the same number of repetitions (outside the timed region)
+        if go_on.item() == 0.0:
+            break
+    seconds = total / repeats
     kernel_ms, launches = rt.timing()
     sky_tiles, my_tiles = rt.sky_tile_stats()
     info = rt.device_info()
@@ -122,7 +138,7 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
     cov_w = W if flags & R.RT_DISPATCH_FULL else (W // 16) * 16
     cov_h = H if flags & R.RT_DISPATCH_FULL else (H // 16) * 16
     samples_per_step = cov_w * cov_h * spp * (world if split == "frames" else 1)
-    return {"seconds": seconds, "kernel_ms": kernel_ms, "launches": launches, "counters": counters,
+    return {"seconds": seconds, "repeats": repeats, "kernel_ms": kernel_ms, "launches": launches, "counters": counters,
             "flops_per_launch": algorithmic_flops(counters), "samples_per_step": samples_per_step, "device": info,
             # samples finished by the sky-tile bound instead of a trace (full 8x8 tiles: the covered area is a multiple of 16),
             # and the algorithmic FLOPs of their primary rays: N + R + n_spheres x T + M per sample
@@ -210,15 +226,21 @@ def main():
     from raytracer_amd import configs
 
     cfg = configs.get(args.config)
-    base_flags = cfg["flags"]
-    if args.split == "frames" and world > 1:
-        base_flags |= R.RT_ACCUM_F32 | R.RT_COMBINE_SUM  # per-GPU frame sums, one reduce, x 1/n afterwards
-    else:
-        base_flags &= ~R.RT_COMBINE_SUM
+    if args.split is None:  # BASELINE: config 3 (and the 1080p ones) by image tiles, config 5 by frame sets
+        args.split = "frames" if args.config == "C5" else "tiles"
 
-    def run(math):
-        flags = base_flags | (R.RT_MATH_FAST if math == "fast" else R.RT_MATH_STRICT)
-        m = measure(R, cfg, flags, rank, world, args.steps, args.warmup, args.split, dist, torch, local_rank, use_dist)
+    def flags_for(split):
+        f = cfg["flags"]
+        if split == "frames" and world > 1:
+            return f | R.RT_ACCUM_F32 | R.RT_COMBINE_SUM  # per-GPU frame sums, one reduce, x 1/n afterwards
+        return f & ~R.RT_COMBINE_SUM
+
+    base_flags = flags_for(args.split)
+
+    def run(math, split=None):
+        split = split or args.split
+        flags = flags_for(split) | (R.RT_MATH_FAST if math == "fast" else R.RT_MATH_STRICT)
+        m = measure(R, cfg, flags, rank, world, args.steps, args.warmup, split, dist, torch, local_rank, use_dist, args.min_seconds)
         sec = torch.tensor([m["seconds"]], dtype=torch.float64, device=f"cuda:{local_rank}")
         if world > 1:
             dist.all_reduce(sec, op=dist.ReduceOp.MAX)
@@ -226,7 +248,9 @@ def main():
         return m
 
     m = run(args.math)
-    extras = per_pass = None
+    extras = per_pass = other_split = None
+    if world > 1 and not args.no_extras:
+        other_split = run(args.math, "frames" if args.split == "tiles" else "tiles")
     if not args.no_extras and world == 1:
         extras = run("fast" if args.math == "strict" else "strict")
         os.environ["RT_DEFER_FRAMES"] = "1"  # read by rt_create
@@ -234,18 +258,22 @@ def main():
         del os.environ["RT_DEFER_FRAMES"]
 
     if rank == 0:
-        def traffic(math, frames_per_launch):
-            # HBM bytes per launch from the committed PMC pass of this same command (profiles/), or null
+        def traffic(math, passes_per_launch, staged):
+            # HBM bytes per launch from the committed PMC pass of this same command (profiles/traffic_*.json holds the
+            # TCC_EA0 byte count of a staged 8-pass launch, PER PASS: a staged launch writes 16 B per pixel and pass,
+            # so its traffic is linear in the passes of the launch), or null where no PMC pass covers the launch shape
             path = os.path.join(ROOT, "profiles", f"traffic_{args.config}_{math}.json")
             try:
                 t = json.load(open(path))
-                return t["bytes_per_launch"] if world == 1 and t.get("frames_per_launch", 1) == frames_per_launch else None
+                if world != 1 or not staged:
+                    return None
+                return t["bytes_per_pass"] * passes_per_launch
             except (OSError, ValueError, KeyError):
                 return None
 
         def roof(mm, math=None):
             launches = max(mm["launches"], 1)
-            fpl = args.steps / launches  # passes (frames) per kernel launch
+            fpl = args.steps * mm["repeats"] / launches  # passes (frames) per kernel launch
             avg_ms = mm["kernel_ms"] / launches
             achieved = mm["flops_per_launch"] * fpl / (avg_ms * 1e-3) / 1e12
             traced = (mm["flops_per_launch"] - mm["sky_flops_per_launch"]) * fpl / (avg_ms * 1e-3) / 1e12
@@ -261,7 +289,7 @@ def main():
                     # the same with the samples the sky-tile bound resolved taken out of the numerator: what the hit loop itself sustains
                     "achieved_traced_only": round(traced, 3), "frac_traced_only": round(traced / FP32_VALU_PEAK_TFLOPS, 4),
                     "sky_tiles": mm["sky_tiles"], "tiles": mm["my_tiles"],
-                    "traffic": traffic(math or args.math, fpl),
+                    "traffic": traffic(math or args.math, fpl, staged),
                     "traffic_algorithmic": int(alg_traffic),
                     "kernel": "rt_path_kernel", "avg_launch_ms": round(avg_ms, 4), "launches": launches, "passes_per_launch": fpl,
                     "algorithmic_flops_per_launch": int(mm["flops_per_launch"] * fpl),
@@ -280,20 +308,30 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": m["seconds"] * 1e3 / args.steps,
+            "repeats": m["repeats"],
             "higher_is_better": True,
-            "scaling": "strong" if (args.split == "tiles" and world > 1) else "weak",
+            "scaling": "n/a" if world == 1 else ("strong" if args.split == "tiles" else "weak"),
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{cfg['name']}: {cfg['description']}", "width": cfg["width"], "height": cfg["height"],
                        "spp": cfg["spp"], "spheres": int(cfg["spheres"].shape[0]), "math": args.math,
-                       "accum": "f32" if base_flags & R.RT_ACCUM_F32 else "rgba8", "split": args.split,
+                       "accum": "f32" if base_flags & R.RT_ACCUM_F32 else "rgba8",
                        "step": "one rt_compute pass (one frame) over the whole image"},
             "rays_per_s": m["counters"]["R"] * (world if args.split == "tiles" else 1) * args.steps / m["seconds"]
             if world == 1 else None,
             "roofline": roof(m),
             "device": m["device"],
         }
+        if world > 1:
+            out["config"]["split"] = args.split
+            out["config"]["parallelism"] = (f"{world} GPUs x interleaved 8x8 tiles of every frame, one RCCL reduce per render" if args.split == "tiles"
+                                            else f"{world} GPUs x disjoint frame sets of the whole image, one RCCL reduce per render")
+        if other_split is not None:
+            osplit = "frames" if args.split == "tiles" else "tiles"
+            out["other_split"] = {"split": osplit, "scaling": "strong" if osplit == "tiles" else "weak",
+                                  "value": other_split["samples_per_step"] * args.steps / other_split["seconds"], "unit": "samples/s",
+                                  "ms_per_step": other_split["seconds"] * 1e3 / args.steps, "repeats": other_split["repeats"]}
         other = "fast" if args.math == "strict" else "strict"
         if extras is not None:
             out[f"{other}_math"] = {"value": extras["samples_per_step"] * args.steps / extras["seconds"], "unit": "samples/s",

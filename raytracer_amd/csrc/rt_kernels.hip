@@ -319,7 +319,13 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   // behind cull: strict small-scene launches (fewer exact tests), and every SPLIT launch (there a bounce ray without
   // candidates is finished on the spot, so candidates that only fall to the exact test cost a loop iteration)
   constexpr bool CULL = SMALL && (STRICT || SPLIT);
-  const uint32_t lane = threadIdx.x;
+  // The lane index is recomputed where the cold code needs it (two v_mbcnt behind a compiler barrier) instead of
+  // living in a register across the hot loop: at 72 registers that one value was the last spill.
+  auto lane_id = []() __attribute__((always_inline)) -> uint32_t {
+    uint32_t l = __builtin_amdgcn_mbcnt_hi(0xffffffffu, __builtin_amdgcn_mbcnt_lo(0xffffffffu, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+  };
   const bool checker = (a.flags & RT_SHADE_CHECKER) != 0;
   const bool accum_f32 = (a.flags & RT_ACCUM_F32) != 0;
   const bool combine_sum = (a.flags & RT_COMBINE_SUM) != 0;
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   __shared__ f32x4 tile_lds[128];  // per wave: 64 pixel records {pixel_center, v<<16|u} {pixel_delta, seed x^y}
   __shared__ f32x4 sph_lds[SMALL ? 3u * RT_SMALL_MAX : 1u];  // SMALL: sph_test | sph_shade | sph_col of the whole scene
   if (SMALL) {
-    for (uint32_t i = lane; i < n_spheres; i += 64u) {
+    for (uint32_t i = threadIdx.x; i < n_spheres; i += 64u) {
       sph_lds[i] = a.sph_test[i];
       sph_lds[RT_SMALL_MAX + i] = a.sph_shade[i];
       sph_lds[2u * RT_SMALL_MAX + i] = a.sph_col[i];
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   //   NEED_DIR -[G]-> GOT_DIR -> READY | PATH_DONE ;  PATH_DONE -[E]-> NEW_RAY | FRAME_END ;  FRAME_END -[F]-> NEW_RAY | NEED_PIXEL ;
   //   NEED_PIXEL -[A]-> DEAD when the queue is empty
   uint32_t state = ST_NEED_PIXEL;
-  size_t pix = 0;            // pixel index v * width + u
+  uint32_t uvp = 0;          // pixel coordinates v << 16 | u (the image index v * width + u is formed where it is used: cold code)
   uint32_t seed_xy = 0;      // pixel part of the RNG seed
   uint32_t my_tile = 0;      // index (in this rank's tile list) of the tile the pixel belongs to
   uint32_t iters = 0;        // trace iterations spent on the current pixel (cost feedback for the tile order)
@@ -359,7 +365,6 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   uint32_t q_mask = 0, q_mask_new = 0xffffffffu;     // wave-uniform: candidate mask of that tile (SPLIT)
   uint32_t tmask = 0;                                // candidate spheres of the primary rays of this lane's pixel (SPLIT)
   float pcx = 0, pcy = 0, pcz = 0, pdx = 0, pdy = 0, pdz = 0;  // pixel_center, pixel_delta
-  float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;                // accumulation pixel
   uint32_t k = 0, rng = 0, sample = 0, depth = 0;
   float sumx = 0, sumy = 0, sumz = 0;                          // send_rays' `color`
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;        // ray (in NEED_DIR / GOT_DIR: d holds the normal)
@@ -621,6 +626,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         p0 = sumx / spp_f; p1 = sumy / spp_f; p2 = sumz / spp_f;
       }
       if (COUNT) c_P++;
+      const size_t pix = (size_t)(uvp >> 16) * ca->width + (uvp & 0xffffu);
       bool done;          // nothing left to do for this lane's unit of work
       bool last_frame;    // the RNG state is the one the capture hook wants
       if (ca->staging) {
@@ -631,18 +637,28 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         done = true;
         last_frame = k + 1u == ca->n_frames;
       } else {
+        // The accumulation pixel is read, combined and written back HERE, per frame (it belongs to this lane for the
+        // whole launch, so the read sees the lane's own previous write): carrying it in four registers across the
+        // frames of a launch cost four registers across the hot loop - and, at 72, spills to scratch memory.
+        float acc0, acc1, acc2, acc3;
+        if (accum_f32) {
+          const f32x4 c = reinterpret_cast<const f32x4*>(ca->accum)[pix];
+          acc0 = c.x; acc1 = c.y; acc2 = c.z; acc3 = c.w;
+        } else {
+          const uint32_t q = reinterpret_cast<const uint32_t*>(ca->accum)[pix];
+          acc0 = unorm8_to_f32(q & 255u); acc1 = unorm8_to_f32((q >> 8) & 255u);
+          acc2 = unorm8_to_f32((q >> 16) & 255u); acc3 = unorm8_to_f32(q >> 24);
+        }
         // cw = f32(frame) / f32(frame + 1) (wgsl:108-109), computed on the host with the same IEEE division
         const float cw = ca->frame_table ? as_f32(ca->frame_table[k].y) : ca->cw0;
         const uint32_t q8 = combine_frame(acc0, acc1, acc2, acc3, p0, p1, p2, cw, combine_sum, accum_f32);
         k++;
         done = last_frame = k == ca->n_frames;
-        if (done) {  // pixel finished: written once per launch
-          if (accum_f32) {
-            f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
-            reinterpret_cast<f32x4*>(ca->accum)[pix] = o;
-          } else {
-            reinterpret_cast<uint32_t*>(ca->accum)[pix] = q8;
-          }
+        if (accum_f32) {
+          f32x4 o; o.x = acc0; o.y = acc1; o.z = acc2; o.w = acc3;
+          reinterpret_cast<f32x4*>(ca->accum)[pix] = o;
+        } else {
+          reinterpret_cast<uint32_t*>(ca->accum)[pix] = q8;
         }
       }
       if (done) {
@@ -662,20 +678,47 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     const unsigned long long need = __ballot(state == ST_NEED_PIXEL);
     if (need) {
       const uint32_t n_need = (uint32_t)__popcll(need);
-      const uint32_t my = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+      // rank of this lane among the needing ones; recomputed per use (two v_mbcnt) rather than kept across the fetch
+      auto my_rank = [&]() __attribute__((always_inline)) -> uint32_t {
+        uint32_t m = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+        asm volatile("" : "+v"(m));
+        return m;
+      };
       const uint32_t avail = q_end - q_cur;
       const bool wants = state == ST_NEED_PIXEL;
-      bool got = false;
-      f32x4 rec0 = {0, 0, 0, 0}, rec1 = {0, 0, 0, 0};
-      uint32_t base = 0xffffffffu, q_frame_new = 0;
+      // the lane takes pixel record `w` of the tile staged in LDS (unit: tile slot `t_slot`, frame `t_frame`)
+      auto take_pixel = [&](uint32_t w, uint32_t t_slot, uint32_t t_frame, uint32_t t_mask) __attribute__((always_inline)) {
+        const f32x4 rec0 = tile_lds[w * 2u], rec1 = tile_lds[w * 2u + 1u];
+        if (as_u32(rec0.w) != 0xffffffffu) {  // else: outside the covered area, the lane takes another slot next round
+          my_tile = t_slot; k = t_frame; tmask = t_mask;
+          pcx = rec0.x; pcy = rec0.y; pcz = rec0.z;
+          pdx = rec1.x; pdy = rec1.y; pdz = rec1.z;
+          uvp = as_u32(rec0.w);
+          seed_xy = as_u32(rec1.w);
+          // k = first frame of this unit: 0, or the unit's frame in a staged launch
+          rng = seed_xy ^ (ca->frame_table ? ca->frame_table[k].x : ca->seed_t0);
+          rng = rng_step(rng);  // initialize_rng's discarded rand() (wgsl:262)
+          if (COUNT) c_rand++;
+          sample = 0; sumx = sumy = sumz = 0.0f;
+          iters = 0;
+          state = ST_NEW_RAY;
+        }
+      };
+      // pixels of the tile already staged in LDS first: their records are consumed before a new tile overwrites them
+      // (and before the fetch below, so that nothing of them stays live across it)
+      {
+        const uint32_t my = my_rank();
+        if (wants && my < avail) take_pixel((q_cur + my) & 63u, q_tile, q_frame, q_mask);
+      }
       if (n_need > avail) {
+        uint32_t base = 0xffffffffu, q_frame_new = 0;
         // Fetch units until one has pixels to hand out. unit -> (tile slot, frame): a staged launch queues every frame
         // of a tile as a unit of its own. Tiles come in the order of the previous launch's measured cost, dearest
         // first, so the launch ends on cheap pixels (results do not depend on the order).
         for (;;) {
           base = 0xffffffffu;
           if (more) {
-            if (lane == 0) base = atomicAdd(ca->queue, 1u);  // all 64 lanes are active here (uniform loop)
+            if (lane_id() == 0u) base = atomicAdd(ca->queue, 1u);  // all 64 lanes are active here (uniform loop)
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= ca->n_units) { more = false; base = 0xffffffffu; }
           }
@@ -693,6 +736,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           // colour (wgsl:174-180, 144-148, 131-134) - no trace.
           const uint32_t tile = q_tile_new * ca->world + ca->rank;
           const uint32_t tx = tile % ca->tiles_x, ty = tile / ca->tiles_x;
+          const uint32_t lane = lane_id();
           const uint32_t pu = tx * 8u + (lane & 7u), pv = ty * 8u + (lane >> 3);
           if (pu < ca->cov_w && pv < ca->cov_h) {
             const float vx = (float)pu, vy = (float)(ca->height - pv);
@@ -757,20 +801,13 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
             if (ca->rng_out && kf1 == ca->n_frames) ca->rng_out[spix] = srng;
           }
         }
-      }
-      if (wants && my < avail) {  // a pixel of the tile already staged in LDS
-        const uint32_t w = (q_cur + my) & 63u;
-        rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
-        my_tile = q_tile; k = q_frame; tmask = q_mask;
-        got = true;
-      }
-      if (n_need > avail) {
         if (base != 0xffffffffu) {
           // ---- stage tile `base`: all 64 lanes compute the per-pixel constants of its 64 pixels at full
           // occupancy (pixel_to_world, get_pixel_delta wgsl:85-94; the pixel part of the RNG seed
           // wgsl:258-259) into LDS; lanes pick their record up when they are handed the pixel.
           const uint32_t tile = q_tile_new * ca->world + ca->rank;
           const uint32_t tx = tile % ca->tiles_x, ty = tile / ca->tiles_x;
+          const uint32_t lane = lane_id();
           const uint32_t pu = tx * 8u + (lane & 7u), pv = ty * 8u + (lane >> 3);
           const float vx = (float)pu, vy = (float)(ca->height - pv);
           const float wx = (float)(pu + 1u), wy = (float)(ca->height - (pv + 1u));
@@ -789,48 +826,17 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           tile_lds[lane * 2u] = w0; tile_lds[lane * 2u + 1u] = w1;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          if (wants && !got) {
-            const uint32_t w = my - avail;
-            rec0 = tile_lds[w * 2u]; rec1 = tile_lds[w * 2u + 1u];
-            my_tile = q_tile_new; k = q_frame_new; tmask = q_mask_new;
-            got = true;
-          }
+          const uint32_t my = my_rank();
+          if (wants && my >= avail) take_pixel(my - avail, q_tile_new, q_frame_new, q_mask_new);
           q_tile = q_tile_new; q_frame = q_frame_new; q_mask = q_mask_new;
           q_cur = base * 64u + (n_need - avail);
           q_end = base * 64u + 64u;
         } else {
+          if (wants && my_rank() >= avail) state = ST_DEAD;  // the queue is empty
           q_cur = q_end;
         }
       } else {
         q_cur += n_need;
-      }
-      if (wants) {
-        if (!got) {
-          state = ST_DEAD;
-        } else if (as_u32(rec0.w) != 0xffffffffu) {  // else: outside the covered area, take another slot next round
-          pcx = rec0.x; pcy = rec0.y; pcz = rec0.z;
-          pdx = rec1.x; pdy = rec1.y; pdz = rec1.z;
-          const uint32_t uvp = as_u32(rec0.w);
-          pix = (size_t)(uvp >> 16) * ca->width + (uvp & 0xffffu);
-          seed_xy = as_u32(rec1.w);
-          if (ca->staging) {
-            // the image is touched by rt_combine_frames_kernel only
-          } else if (accum_f32) {
-            const f32x4 c = reinterpret_cast<const f32x4*>(ca->accum)[pix];
-            acc0 = c.x; acc1 = c.y; acc2 = c.z; acc3 = c.w;
-          } else {
-            const uint32_t q = reinterpret_cast<const uint32_t*>(ca->accum)[pix];
-            acc0 = unorm8_to_f32(q & 255u); acc1 = unorm8_to_f32((q >> 8) & 255u);
-            acc2 = unorm8_to_f32((q >> 16) & 255u); acc3 = unorm8_to_f32(q >> 24);
-          }
-          // k = first frame of this unit: 0, or the unit's frame in a staged launch (set at the hand-out above)
-          rng = seed_xy ^ (ca->frame_table ? ca->frame_table[k].x : ca->seed_t0);
-          rng = rng_step(rng);  // initialize_rng's discarded rand() (wgsl:262)
-          if (COUNT) c_rand++;
-          sample = 0; sumx = sumy = sumz = 0.0f;
-          iters = 0;
-          state = ST_NEW_RAY;
-        }
       }
     }
     if (!__ballot(state != ST_DEAD)) break;  // every lane drained and the queue is empty (lanes die in [A] only)
@@ -970,7 +976,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
 
   const rt_kargs_cptr ca = cold_args();
 #if RT_PROFILE_SECTIONS
-  if (lane == 0) {
+  if (lane_id() == 0u) {
     const unsigned long long life = __builtin_amdgcn_s_memtime() - prof_start;
     const unsigned long long rlife = __builtin_amdgcn_s_memrealtime() - prof_rstart;  // 100 MHz
     const unsigned long long pv[8] = {prof_acc0, prof_acc1, prof_acc2, prof_acc3, prof_acc4, life, prof_iters, rlife};
@@ -989,7 +995,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     const uint32_t vals[12] = {c_T, c_D, c_H, c_R, c_M, c_S, c_Sm, c_J, c_Sd, c_N, c_P, c_rand};
 #pragma unroll
     for (int i = 0; i < 12; ++i) atomicAdd(&ca->counters[i], (unsigned long long)vals[i]);
-    if (lane == 0) {
+    if (lane_id() == 0u) {
       atomicAdd(&ca->counters[12], 64ull * c_wt);
       atomicAdd(&ca->counters[13], 64ull * c_wr);
     }

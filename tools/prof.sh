@@ -6,7 +6,7 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 # 8 + 8 passes: the library runs them as two 8-pass launches (RT_DEFER_FRAMES), like the default bench command
-cmd="bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-extras $*"
+cmd="bench.py --steps 8 --warmup 8 --min-seconds 0 --no-cpu-baseline --no-extras $*"
 export PROF_FRAMES_PER_LAUNCH=${RT_DEFER_FRAMES:-8}
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $cmd > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \

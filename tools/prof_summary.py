@@ -39,6 +39,7 @@ for k in sums:
         t = {"kernel": k, "rdreq_per_launch": rd, "wrreq_per_launch": wr, "bytes_per_launch": rd * 128 + wr * 64,
              "cost_measuring_launch_bytes": max(each[k]["TCC_EA0_RDREQ_sum"]) * 128 + max(each[k]["TCC_EA0_WRREQ_sum"]) * 64,
              "launches": len(each[k]["TCC_EA0_RDREQ_sum"]), "frames_per_launch": int(os.environ.get("PROF_FRAMES_PER_LAUNCH", "1")),
+             "bytes_per_pass": (rd * 128 + wr * 64) / int(os.environ.get("PROF_FRAMES_PER_LAUNCH", "1")),
              "rule": "RDREQ x 128 B + WRREQ x 64 B (separate --pmc pass, TCC_EA0_RDREQ_sum / TCC_EA0_WRREQ_sum), median launch"}
         json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
         print("traffic:", t)
