@@ -76,8 +76,18 @@ def test_c2_full_size_frame_bit_exact_and_properties():
         O.compute(img, spheres, mats, cam, int(tb[f]))
         assert np.array_equal(rt.read_rng_state(), img.rng), f"frame {f}"
         assert np.array_equal(rt.read_rgba8(), img.rgba8), f"frame {f}"
-    # KAT from SURVEY.md §8c: pixel (1919,1071) of frame 3 starts from seed 0x83646972
-    assert img.rng[1071, 1919] != 0
+    # KAT from SURVEY.md §8c for pixel (1919, 1071) of frame 3: time bits 0x3d23d70a, seed 0x83646972, state after the
+    # discarded rand() 0x43532a6b - re-derived here from raytrace_kernal.wgsl:255-275 in plain integer arithmetic, and
+    # the host's time table must be the one that feeds it (the pixel's FINAL state was compared with the oracle above)
+    assert int(tb[3]) == 0x3D23D70A
+    u, v, M = 1919, 1071, 0xFFFFFFFF
+    seed = (((u << 15) & M) ^ ((u * 1729 + 8192374) & M)) ^ (((v << 21) & M) ^ ((v * 271 + 719827371) & M)) ^ ((int(tb[3]) * 87189 + 189273) & M)
+    assert seed == 0x83646972
+    x = (seed * 18197 + 182489729) & M
+    x ^= (x << 15) & M; x ^= x >> 22; x ^= (x << 4) & M
+    assert x == 0x43532A6B
+    from np_oracle import _Rng
+    assert int(_Rng(np.array([u], np.uint32), np.array([v], np.uint32), int(tb[3])).state[0]) == x
     out = rt.read_rgba8()
     assert not out[1072:].any() and (out[:1072, :, 3] == 255).all()  # 1080/16 = 67.5 -> rows 1072.. untouched
     rt.close()
@@ -177,3 +187,55 @@ def test_full_size_configs_match_the_oracles_checksums(name, mode):
     if flags & O.ACCUM_F32:
         assert hashlib.sha256(rt.read_accum_f32().tobytes()).hexdigest() == want["accum_sha256"]
     rt.close()
+
+
+@pytest.mark.parametrize("name,frames", [("C3", 8), ("C4", 128)])
+def test_fast_math_tolerance_at_baseline_size(name, frames):
+    """RT_MATH_FAST at BASELINE's full size against the strict render of the same run (strict is pinned to the oracle's
+    SHA-256 digests by test_full_size_configs_match_the_oracles_checksums): the north star's tolerance on the CONVERGED
+    float image - PSNR >= 40 dB, at most 2 % of the pixels off by more than 3/255 - and the share of pixels whose final
+    RNG state (last frame) is identical. C3 = 3840x2160, 64 spp, 8 frames (512 samples per pixel): >= 99 % identical
+    (measured 99.3 %, 60.8 dB, 0.08 % outliers).
+    C4 = 1920x1080, 1024 spheres, 4 spp, run for 128 frames here (512 samples per pixel) DOES NOT MEET that bar and the
+    test pins what it does meet: 91.5 % identical per frame, 39.3 dB, 3.0 % outliers - and the difference is
+    systematic, not noise (38.3 dB at 16 frames). Its spheres sit 30-70 units from the ray origins with radius 1, so the
+    literal c = length_squared(oc) - r*r carries an absolute error of ~3e-4 (sqrt-then-square of ~2500) and the
+    discriminant hb^2 - a c cancels ~2500:1: silhouette decisions within ~2e-4 r and, on grazing bounces, the second
+    root of the sphere the ray starts on (|c| / 2 hb against tmin = 1e-3: "shadow acne") are decided by rounding.
+    RT_MATH_STRICT reproduces the literal roundings bit for bit; RT_MATH_FAST (FMA, dot for length_squared) is a
+    different, smaller set of roundings and renders a different acne pattern. The same holds for any real WGSL driver
+    (contraction is its choice). Fast mode is therefore documented as within tolerance for scenes whose spheres are
+    within a few radii of the rays' origins (C1-C3, C5), not for C4."""
+    import raytracer_amd as R
+    from raytracer_amd import configs, host
+
+    cfg = configs.get(name)
+    W, H, spp = cfg["width"], cfg["height"], cfg["spp"]
+    flags = cfg["flags"] | R.RT_ACCUM_F32
+    tb = host.time_table(frames)
+
+    def render(math):
+        rt = R.Raytracer(W, H, flags | math)
+        rt.set_scene(cfg["spheres"], cfg["materials"])
+        rt.enable_rng_capture(True)
+        rt.set_camera(host.camera_raw(W, H, spp=spp, frames=frames))
+        rt.render_frames(tb)
+        out = np.clip(rt.read_accum_f32()[..., :3], 0, 1), rt.read_rng_state()
+        rt.close()
+        return out
+
+    ref, ref_rng = render(R.RT_MATH_STRICT)
+    got, got_rng = render(R.RT_MATH_FAST)
+    cov = (H // 16) * 16
+    same = got_rng[:cov] == ref_rng[:cov]
+    err = np.abs(got - ref).max(axis=-1)[:cov]
+    mse = float(np.mean((got[:cov] - ref[:cov]) ** 2))
+    psnr = 99.0 if mse == 0 else 10.0 * np.log10(1.0 / mse)
+    print(f"fast vs strict at full size [{name}]: rng-identical {same.mean():.6f}, PSNR {psnr:.1f} dB, "
+          f"max-abs on identical-trajectory pixels {err[same].max():.6f}, pixels over 3/255: {np.mean(err > 3.0 / 255.0):.6f}")
+    assert ref_rng[:cov].all() and same.mean() >= (0.99 if name == "C3" else 0.90)
+    assert psnr >= (40.0 if name == "C3" else 38.0)
+    # mirror-to-mirror chains are chaotic (a 1-ulp change grows ~10x per bounce), the checker gate is a step function of
+    # the normal, and "identical final state" speaks of the last frame only: a pixel can change colour without showing
+    # in the RNG comparison, so the outlier FRACTION is bounded (the small-size test uses the same bound)
+    assert np.mean(err > 3.0 / 255.0) <= (0.02 if name == "C3" else 0.05)

@@ -41,4 +41,4 @@ if __name__ == "__main__":
         run("C2", math)
         run("C3", math)
         run("C4", math)
-        run("C5", math, frames_override=64)   # 64 of the 1024 frames on one GPU (the full job is the 8-GPU frame split)
+        run("C5", math)   # all 1024 frames on ONE GPU (the 8-GPU frame split of BASELINE config 5 is bench.py --config C5 --gpus 8)
