@@ -88,7 +88,8 @@ struct rt_ctx {
   uint32_t order_age = 0;     // launches since the cost was last measured
   int use_order = 1;          // env RT_TILE_ORDER=0 disables the feedback
   // sky tiles: per-tile "no primary ray can hit a sphere" flags for the current scene, camera and partition
-  uint32_t* sky_flags = nullptr;
+  uint32_t* sky_flags = nullptr;   // tile masks (0 = sky tile)
+  uint16_t* tile_lists = nullptr;  // scenes of > 32 spheres: 16 x u16 per tile (rt_kargs::tile_lists), sized like sky_flags
   uint32_t sky_tiles_cap = 0;  // my_tiles the buffer is sized for
   uint32_t sky_key = 0;        // rank/world the flags were computed under
   bool sky_valid = false;
@@ -294,30 +295,34 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     // the scratch is shared by every context on this GPU and keeps the last call's contents: the flags of this
     // context's my_tiles tiles are rewritten by every call (15 us at 4K)
     uint32_t* flags = reinterpret_cast<uint32_t*>(scratch + RT_STATIC_OFF_SKY);
-    RT_HIP(rt_launch_tile_masks(a, flags, ctx->stream));
+    RT_HIP(rt_launch_tile_masks(a, flags, nullptr, ctx->stream));  // no room for candidate lists in the static scratch
     a.tile_masks = flags;
   } else if (ctx->use_sky && !ctx->counting) {
     if (ctx->sky_tiles_cap != my_tiles) {
       RT_HIP(hipStreamSynchronize(ctx->stream));
       (void)hipFree(ctx->sky_flags);
+      (void)hipFree(ctx->tile_lists);
       ctx->sky_flags = nullptr;
+      ctx->tile_lists = nullptr;
       ctx->sky_tiles_cap = 0;
       RT_HIP(hipMalloc((void**)&ctx->sky_flags, my_tiles * sizeof(uint32_t)));
+      RT_HIP(hipMalloc((void**)&ctx->tile_lists, (size_t)my_tiles * 16u * sizeof(uint16_t)));
       ctx->sky_tiles_cap = my_tiles;
       ctx->sky_valid = false;
     }
     if (ctx->sky_key != key) ctx->sky_valid = false;
     ctx->sky_key = key;
     if (!ctx->sky_valid) {
-      RT_HIP(rt_launch_tile_masks(a, ctx->sky_flags, ctx->stream));
+      RT_HIP(rt_launch_tile_masks(a, ctx->sky_flags, ctx->tile_lists, ctx->stream));
       ctx->sky_valid = true;
     }
     a.tile_masks = ctx->sky_flags;
+    if (a.n_spheres > 64u /* RT_SMALL_MAX */ && a.n_spheres <= 0xfff0u) a.tile_lists = ctx->tile_lists;
   }
   RT_HIP(hipMemsetAsync(a.queue, 0, sizeof(uint32_t), ctx->stream));
   if (timing) RT_HIP(hipEventRecord(e0, ctx->stream));
   // SPLIT variant (primary rays traced against their tile's candidate mask, primary + first bounce per iteration)
-  const bool split = ctx->use_split && a.tile_masks && !ctx->counting && a.n_spheres <= 32u;
+  const bool split = ctx->use_split && a.tile_masks && !ctx->counting && (a.n_spheres <= 32u || a.tile_lists);
   RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, split, ctx->stream));
   if (timing) {
     RT_HIP(hipEventRecord(e1, ctx->stream));
@@ -485,6 +490,7 @@ void rt_destroy(rt_ctx* c) {
   (void)hipFree(c->tile_cost);
   (void)hipFree(c->tile_order);
   (void)hipFree(c->sky_flags);
+  (void)hipFree(c->tile_lists);
   (void)hipFree(c->sph_p1);
   (void)hipFree(c->sph_test);
   (void)hipFree(c->sph_shade);

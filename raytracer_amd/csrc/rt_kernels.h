@@ -47,14 +47,19 @@ struct rt_kargs {
   uint32_t* tile_cost;           // optional: per-tile trace iterations of this launch (zeroed before it)
   const uint32_t* tile_masks;    // optional, per tile of this rank (rt_tile_masks_kernel): 0 = sky tile (no primary ray can hit a sphere),
                                  // else the spheres its primary rays can hit (<= 32 spheres: bit cnt_pad-1-i; else all ones)
+  const uint16_t* tile_lists;    // optional, scenes of > 32 spheres, 16 x u16 per tile of this rank: [0] = number of spheres a
+                                 // primary ray of the tile can hit (<= 15; 0xffff = more, or rays not provably tame), [1..] their
+                                 // indices in ascending order
 };
 
 // n_waves persistent single-wave workgroups pull tiles from a.queue until a.my_tiles are handed out
-// split: the SPLIT variant (primary rays traced against their tile's mask; needs a.tile_masks, <= 32 spheres, !count)
+// split: a SPLIT variant - primary rays traced against their tile's candidates: a.tile_masks for <= 32 spheres, a.tile_lists
+// for > 64 (RT_SMALL_MAX); never for counting launches
 hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, bool split, hipStream_t stream);
 // folds the staged frame colours into the accumulation image, in frame order, for the pixels of this rank's tiles
 hipError_t rt_launch_combine_frames(const rt_kargs& a, hipStream_t stream);
-// masks[j] = spheres a primary ray of this rank's j-th tile can hit, 0 for a sky tile (conservative, double precision)
-hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, hipStream_t stream);
+// masks[j] = spheres a primary ray of this rank's j-th tile can hit, 0 for a sky tile (conservative, double precision);
+// lists (optional, scenes of > 32 spheres): the same as a short list per tile (rt_kargs::tile_lists)
+hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, uint16_t* lists, hipStream_t stream);
 hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t n, hipStream_t stream);
 hipError_t rt_launch_quantize(const void* src_f32x4, void* dst_rgba8, size_t n_pixels, hipStream_t stream);

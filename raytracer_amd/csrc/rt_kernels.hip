@@ -315,10 +315,12 @@ template <bool STRICT, bool COUNT, bool SMALL, bool SPLIT>
 #define RT_SPLIT_WAVES 7
 #endif
 __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7) : RT_MIN_WAVES) void rt_path_kernel(const rt_kargs a) {
-  static_assert(!SPLIT || (SMALL && !COUNT), "SPLIT needs the tile masks, which counting launches do not use");
+  static_assert(!SPLIT || !COUNT, "SPLIT needs the tile masks / lists, which counting launches do not use");
+  constexpr bool MASK = SPLIT && SMALL;   // <= 32 spheres: the tile's candidates are a bit mask, every section once per iteration
+  constexpr bool LIST = SPLIT && !SMALL;  // > 64 spheres: the tile's candidates are a short list; primary and general trace
   // behind cull: strict small-scene launches (fewer exact tests), and every SPLIT launch (there a bounce ray without
   // candidates is finished on the spot, so candidates that only fall to the exact test cost a loop iteration)
-  constexpr bool CULL = SMALL && (STRICT || SPLIT);
+  constexpr bool CULL = SMALL && (STRICT || SPLIT);  // (the 1024-sphere scene loses 2 % with it: one more instruction per sphere)
   // The lane index is recomputed where the cold code needs it (two v_mbcnt behind a compiler barrier) instead of
   // living in a register across the hot loop: at 72 registers that one value was the last spill.
   auto lane_id = []() __attribute__((always_inline)) -> uint32_t {
@@ -398,14 +400,15 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   //    With dub <= 2^-11 hb and hb <= 2048 a that is <= (2.45e-4 + 2.57e-4)(1 + 6u) < tmin = 1e-3: rejected; root1 < 0.
   // So under `drop` hit_sphere returns false for `own` in the literal arithmetic (it has no side effect then), and the
   // sphere leaves the candidate set. Grazing departures (hb tiny) and rays from huge spheres keep their exact test.
-  auto own_sphere_bit = [&]() __attribute__((always_inline)) -> uint32_t {
-    const f32x4 so = sph_lds[own];  // {c, fl(r r)}
+  auto own_sphere_drop = [&]() __attribute__((always_inline)) -> bool {
+    const bool has_own = own != 0xffffffffu;  // LIST: a primary ray that takes the general trace (its tile's list overflowed)
+    const uint32_t oi = has_own ? own : 0u;
+    const f32x4 so = SMALL ? sph_lds[oi] : a.sph_test[oi];  // {c, fl(r r)}
     const float ex = ox - so.x, ey = oy - so.y, ez = oz - so.z;
     const float x = STRICT ? dot_strict(ex, ey, ez, ex, ey, ez) : dot_fast(ex, ey, ez, ex, ey, ez);
     const float hbo = STRICT ? dot_strict(ex, ey, ez, dx, dy, dz) : dot_fast(ex, ey, ez, dx, dy, dz);
     const float dub = __builtin_fmaf(x, 0x1p-20f, so.w - x);
-    const bool drop = tame && hbo >= 0x1p-30f && dub <= 0x1p-11f * hbo && hbo <= 2048.0f * a_lit;
-    return drop ? 1u << (n_pad32 - 1u - own) : 0u;
+    return has_own && tame && hbo >= 0x1p-30f && dub <= 0x1p-11f * hbo && hbo <= 2048.0f * a_lit;
   };
 
   // [P] per-ray prelude; FILTER: also the per-ray terms of the phase-1 filter ("phase-1 filter"):
@@ -444,15 +447,9 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   // is below div_core's upper limit, and a numerator under its lower limit 2^-60 gives |quotient| < 2^-38 both
   // exactly and from div_core - far below RT_RAY_TMIN, where only the comparison `root <= tmin` is used.
   // Untamed rays take the compiler's division.
-  auto walk = [&](uint32_t base, uint32_t cnt_pad, float& closest, int& hit, unsigned long long any_untame) __attribute__((always_inline)) {
+  auto test_sphere = [&](uint32_t i, float& closest, int& hit, unsigned long long any_untame) __attribute__((always_inline)) {
     const rn_divisor a_div = {a_lit, a_rcp, false};
-    while (cand) {
-#if RT_PROFILE_SECTIONS
-      prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true));
-#endif
-      const uint32_t lz = (uint32_t)__builtin_clz(cand);
-      cand &= ~(0x80000000u >> lz);
-      const uint32_t i = base + cnt_pad - 32u + lz;
+    {
       const f32x4 s = SMALL ? sph_lds[i] : a.sph_test[i];
       const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
       if (STRICT) {
@@ -485,6 +482,16 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           if (root > RT_RAY_TMIN && root < closest) { closest = root; hit = (int)i; }
         }
       }
+    }
+  };
+  auto walk = [&](uint32_t base, uint32_t cnt_pad, float& closest, int& hit, unsigned long long any_untame) __attribute__((always_inline)) {
+    while (cand) {
+#if RT_PROFILE_SECTIONS
+      prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true));
+#endif
+      const uint32_t lz = (uint32_t)__builtin_clz(cand);
+      cand &= ~(0x80000000u >> lz);
+      test_sphere(base + cnt_pad - 32u + lz, closest, hit, any_untame);
     }
   };
 
@@ -595,6 +602,50 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     state = depth > (uint32_t)RT_MAX_RAY_DEPTH ? ST_PATH_DONE : ST_READY;  // for (depth = 0; depth <= MAX_RAY_DEPTH; depth++) (wgsl:131)
   };
   const uint32_t valid32 = (n_pad32 >= 32u ? 0xffffffffu : (1u << n_pad32) - 1u) & ~((1u << (n_pad32 - (n_spheres < 32u ? n_spheres : 32u) & 31u)) - 1u);
+
+  // [C] the general trace: prelude, then per block of 32 spheres phase 1 and the walk of its candidates, then miss or scatter
+  auto trace_general = [&]() __attribute__((always_inline)) {
+    if (COUNT && __ballot(state == ST_READY)) c_wt++;
+    if (state == ST_READY) {
+      RT_PROF_BEGIN(1);
+      iters++;
+      float closest = RT_RAY_TMAX;
+      int hit = -1;
+      p1_ray p1q;
+      ray_prelude(std::integral_constant<bool, true>{}, p1q);
+      const unsigned long long any_untame = __ballot(!tame);
+      const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
+      const bool own_drop = LIST ? own_sphere_drop() : false;
+      if (COUNT) { c_R++; c_T += n_spheres; }
+      RT_PROF_END(1);
+      for (uint32_t base = 0; base < n_spheres; base += 32u) {
+        const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
+        // ---- phase 1: sign of D + M for spheres base..base+cnt-1 -> bitmask ----
+        // bit (cnt_pad-1-j) of `missbits` = sign of sphere (base+j)'s value (1 = certain miss)
+        const uint32_t cnt_pad = (cnt + 3u) & ~3u;
+        RT_PROF_BEGIN(2);
+        const uint32_t missbits = phase1_missbits<CULL>(sph_p1, base, cnt_pad, p1q);
+#if RT_PROFILE_SECTIONS
+        asm volatile("" :: "v"(missbits));  // keep the loop inside the timed region
+#endif
+        RT_PROF_END(2);
+        RT_PROF_BEGIN(3);
+        // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
+        // (untamed rays take every sphere; the lowest cnt_pad - cnt bits are padding spheres)
+        const uint32_t valid = (cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u);  // wave-uniform
+        cand = (~missbits | untame_fill) & valid;
+        if (LIST) {  // own-sphere drop (see own_sphere_drop): the sphere the ray starts on, when it is in this block
+          const uint32_t rel = own - base;
+          if (own_drop && rel < cnt) cand &= ~(1u << (cnt_pad - 1u - rel));
+        }
+        walk(base, cnt_pad, closest, hit, any_untame);
+        RT_PROF_END(3);
+      }
+      RT_PROF_BEGIN(4);
+      if (hit < 0) shade_miss(); else shade_hit(closest, hit);
+      RT_PROF_END(4);
+    }
+  };
 
   for (;;) {
 #if RT_PROFILE_SECTIONS
@@ -875,43 +926,8 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       }
       if (state == ST_GOT_DIR) finish_direction();
       RT_PROF_END(0);
-      // ---- [C] trace + shade (lanes with a ray) ----
-      if (COUNT && __ballot(state == ST_READY)) c_wt++;
-      if (state == ST_READY) {
-        RT_PROF_BEGIN(1);
-        iters++;
-        float closest = RT_RAY_TMAX;
-        int hit = -1;
-        p1_ray p1q;
-        ray_prelude(std::integral_constant<bool, true>{}, p1q);
-        const unsigned long long any_untame = __ballot(!tame);
-        const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
-        if (COUNT) { c_R++; c_T += n_spheres; }
-        RT_PROF_END(1);
-        for (uint32_t base = 0; base < n_spheres; base += 32u) {
-          const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
-          // ---- phase 1: sign of D + M for spheres base..base+cnt-1 -> bitmask ----
-          // bit (cnt_pad-1-j) of `missbits` = sign of sphere (base+j)'s value (1 = certain miss)
-          const uint32_t cnt_pad = (cnt + 3u) & ~3u;
-          RT_PROF_BEGIN(2);
-          const uint32_t missbits = phase1_missbits<CULL>(sph_p1, base, cnt_pad, p1q);
-#if RT_PROFILE_SECTIONS
-          asm volatile("" :: "v"(missbits));  // keep the loop inside the timed region
-#endif
-          RT_PROF_END(2);
-          RT_PROF_BEGIN(3);
-          // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
-          // (untamed rays take every sphere; the lowest cnt_pad - cnt bits are padding spheres)
-          const uint32_t valid = (cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u);  // wave-uniform
-          cand = (~missbits | untame_fill) & valid;
-          walk(base, cnt_pad, closest, hit, any_untame);
-          RT_PROF_END(3);
-        }
-        RT_PROF_BEGIN(4);
-        if (hit < 0) shade_miss(); else shade_hit(closest, hit);
-        RT_PROF_END(4);
-      }
-    } else {
+      trace_general();
+    } else if (MASK) {
       // SPLIT SHAPE (scenes of <= 32 spheres whose launch has per-tile candidate masks; DESIGN.md, "primary / bounce
       // split"). Every section appears once, and a lane passes through up to two rays per iteration:
       //   [G0] NEW_RAY: jitter draws, prelude; candidates := the tile's mask (no phase 1: every sphere outside the mask
@@ -966,11 +982,52 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         RT_PROF_END(1);
         RT_PROF_BEGIN(2);
         const uint32_t missbits = phase1_missbits<CULL>(sph_p1, 0u, n_pad32, p1q);
-        cand = (~missbits | (tame ? 0u : 0xffffffffu)) & valid32 & ~own_sphere_bit();
+        cand = (~missbits | (tame ? 0u : 0xffffffffu)) & valid32 & ~(own_sphere_drop() ? 1u << (n_pad32 - 1u - own) : 0u);
         state = ST_TEST;
         if (cand == 0u) shade_miss();
         RT_PROF_END(2);
       }
+    } else {
+      // LIST SHAPE (scenes of more than 64 spheres with per-tile candidate LISTS, rt_tile_masks_kernel): the primary ray
+      // walks its tile's list - the up to 15 spheres a primary ray of the tile can hit - instead of running phase 1 over
+      // the whole scene; the general trace [C] then serves the bounce rays (and the primary rays of the few tiles whose
+      // list overflowed), with the own-sphere drop. A lane passes its primary and its first bounce ray through one
+      // iteration, and phase 1 - two thirds of the time of the 1024-sphere scene - runs for bounce rays only.
+      RT_PROF_BEGIN(0);
+      uint32_t lcnt = 0;
+      if (state == ST_NEW_RAY) {
+        uint32_t s0, s1;
+        RT_STEP(s0); RT_STEP(s1);
+        start_ray(s0, s1);
+        own = 0xffffffffu;
+        lcnt = a.tile_lists[(size_t)my_tile * 16u];
+        state = lcnt > 15u ? ST_READY : ST_TEST;  // 0xffff: the list overflowed (or the tile's rays are not provably tame)
+      }
+      RT_PROF_END(0);
+      RT_PROF_BEGIN(3);
+      if (state == ST_TEST) {
+        p1_ray unused;
+        iters++;
+        ray_prelude(std::integral_constant<bool, false>{}, unused);
+        float closest = RT_RAY_TMAX;
+        int hit = -1;
+        const unsigned long long any_untame = __ballot(!tame);
+        const uint16_t* list = a.tile_lists + (size_t)my_tile * 16u + 1u;
+        for (uint32_t j = 0; j < lcnt; ++j) test_sphere(list[j], closest, hit, any_untame);  // ascending sphere index
+        if (hit < 0) shade_miss(); else shade_hit(closest, hit);
+      }
+      RT_PROF_END(3);
+      RT_PROF_BEGIN(0);
+      for (uint32_t round = 0; round < a.reject_tries && __ballot(state == ST_NEED_DIR) != 0ull; ++round) {
+        if (state == ST_NEED_DIR) {
+          uint32_t s0, s1, s2;
+          RT_STEP(s0); RT_STEP(s1); RT_STEP(s2);
+          try_direction(s0, s1, s2);
+        }
+      }
+      if (state == ST_GOT_DIR) finish_direction();
+      RT_PROF_END(0);
+      trace_general();
     }
   }
 
@@ -1050,7 +1107,7 @@ __global__ __launch_bounds__(256) void rt_combine_frames_kernel(const rt_kargs a
 //        discriminant is below -2^-12 a S and the literal one (within 54 2^-24 a S of it) is negative; or
 //   (B)  cos(psi - theta) < -2^-8: the sphere lies behind every ray, literal half_b > 0 and c > 0, both roots <= 0 <= tmin.
 //   Rays must be `tame` (no overflow / underflow in the literal code): |d|^2 in [2^-19, 2^19], |o|^2 <= 2^39, tame scene.
-__global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, uint32_t* __restrict__ masks) {
+__global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, uint32_t* __restrict__ masks, uint16_t* __restrict__ lists) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= a.my_tiles) return;
   const uint32_t tile = j * a.world + a.rank;
@@ -1081,8 +1138,11 @@ __global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, ui
   const uint32_t cnt_pad = per_sphere ? (a.n_spheres + 3u) & ~3u : 32u;
   const uint32_t everything = per_sphere ? (cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - a.n_spheres)) - 1u) : 0xffffffffu;
   uint32_t mask = everything;  // the rays are not provably tame: every sphere stays a candidate
+  uint32_t n_list = 0xffffu;   // > 32 spheres: length of the tile's candidate list, 0xffff = no list (overflow / not tame)
+  uint16_t* list = lists && !per_sphere ? lists + (size_t)j * 16u : nullptr;
   if (ok) {  // also false for NaN / inf in the columns used above
     mask = 0u;
+    n_list = 0u;
     const double sin_t = rho / ndc, cos_t = sqrt(1.0 - sin_t * sin_t);
     for (uint32_t i = 0; i < a.n_spheres; ++i) {
       const rt_f32x4 sp = a.sph_shade[i];
@@ -1100,12 +1160,19 @@ __global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, ui
         miss = clear || behind;
       }
       if (!miss) {
-        if (!per_sphere) { mask = everything; break; }
-        mask |= 1u << (cnt_pad - 1u - i);
+        if (per_sphere) {
+          mask |= 1u << (cnt_pad - 1u - i);
+        } else {
+          mask = everything;
+          if (!list) break;                      // only "sky tile or not" is wanted
+          if (n_list >= 15u) { n_list = 0xffffu; break; }
+          list[1u + n_list++] = (uint16_t)i;     // ascending index: the order hit_sphere's tie rule needs
+        }
       }
     }
   }
   masks[j] = mask;
+  if (list) list[0] = (uint16_t)n_list;
 }
 
 // Tile order for the next launch: counting sort of this launch's per-tile cost, dearest first.
@@ -1152,20 +1219,22 @@ __global__ void rt_quantize_kernel(const f32x4* __restrict__ src, uint32_t* __re
 hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool strict, bool count, bool split, hipStream_t stream) {
   if (n_waves == 0 || a.my_tiles == 0) return hipSuccess;
   const dim3 grid(n_waves), block(64);
-  // SPLIT needs what makes its primary section correct: candidate masks (<= 32 spheres, a non-counting launch)
-  if (split && (count || !a.tile_masks || a.n_spheres > 32u)) return hipErrorInvalidValue;
+  // SPLIT needs what makes its primary section correct: candidate masks (<= 32 spheres) or lists (> RT_SMALL_MAX), no counting
+  const bool small = a.n_spheres <= RT_SMALL_MAX;
+  if (split && (count || !a.tile_masks || (a.n_spheres > 32u && (small || !a.tile_lists)))) return hipErrorInvalidValue;
   // SMALL variants while the scene fits their LDS arrays. The behind cull they carry in strict mode saves exact tests
   // for one more instruction per sphere test (measured: 20 spheres -3 %, 1024 spheres +2 %). Counting launches keep
   // every candidate: the oracle's D counts their discriminants.
-  const bool small = a.n_spheres <= RT_SMALL_MAX;
   if (strict) {
     if (count) hipLaunchKernelGGL((rt_path_kernel<true, true, false, false>), grid, block, 0, stream, a);
-    else if (split) hipLaunchKernelGGL((rt_path_kernel<true, false, true, true>), grid, block, 0, stream, a);
+    else if (split && small) hipLaunchKernelGGL((rt_path_kernel<true, false, true, true>), grid, block, 0, stream, a);
+    else if (split) hipLaunchKernelGGL((rt_path_kernel<true, false, false, true>), grid, block, 0, stream, a);
     else if (small) hipLaunchKernelGGL((rt_path_kernel<true, false, true, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rt_path_kernel<true, false, false, false>), grid, block, 0, stream, a);
   } else {
     if (count) hipLaunchKernelGGL((rt_path_kernel<false, true, false, false>), grid, block, 0, stream, a);
-    else if (split) hipLaunchKernelGGL((rt_path_kernel<false, false, true, true>), grid, block, 0, stream, a);
+    else if (split && small) hipLaunchKernelGGL((rt_path_kernel<false, false, true, true>), grid, block, 0, stream, a);
+    else if (split) hipLaunchKernelGGL((rt_path_kernel<false, false, false, true>), grid, block, 0, stream, a);
     else if (small) hipLaunchKernelGGL((rt_path_kernel<false, false, true, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rt_path_kernel<false, false, false, false>), grid, block, 0, stream, a);
   }
@@ -1179,9 +1248,10 @@ hipError_t rt_launch_combine_frames(const rt_kargs& a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, hipStream_t stream) {
+hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, uint16_t* lists, hipStream_t stream) {
   if (a.my_tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(rt_tile_masks_kernel, dim3((a.my_tiles + 255u) / 256u), dim3(256), 0, stream, a, masks);
+  if (lists && a.n_spheres > 0xfff0u) lists = nullptr;  // list entries are 16 bits
+  hipLaunchKernelGGL(rt_tile_masks_kernel, dim3((a.my_tiles + 255u) / 256u), dim3(256), 0, stream, a, masks, lists);
   return hipGetLastError();
 }
 

@@ -808,6 +808,27 @@ def test_moved_zoomed_host_camera_through_the_app_equals_the_oracle():
     app.close()
 
 
+@pytest.mark.parametrize("n,W,H,fov", [(100, 256, 160, 0.25), (300, 320, 192, 0.1), (1024, 192, 128, 0.02)],
+                         ids=["100_wide", "300_mid", "1024_narrow"])
+def test_list_shape_candidate_lists_short_long_and_overflowing(n, W, H, fov, monkeypatch):
+    """Scenes of more than 64 spheres trace their primary rays against per-tile candidate LISTS (<= 15 entries, else
+    the general trace): a wide view makes most lists overflow, a narrow one makes them short. Bit-exact against the
+    oracle either way, and equal to the kernel without the split."""
+    R = _rt()
+    sp, mt = scenes.random_bunch(n, 5, 11)
+    frames = 3
+    cam = scenes.camera_raw(W, H, spp=3, frames=frames, fov=fov)
+    img = O.OracleImage(W, H, O.ACCUM_F32)
+    O.render(img, sp, mt, cam, 0, frames)
+    for split in ("1", "0"):
+        monkeypatch.setenv("RT_SPLIT", split)
+        for batched in (False, True):
+            rt = _run_gpu(R, W, H, O.ACCUM_F32, sp, mt, cam, frames, batched=batched)
+            assert np.array_equal(rt.read_rng_state(), img.rng), (split, batched)
+            assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32)), (split, batched)
+            rt.close()
+
+
 def test_sky_tiles_are_off_for_a_non_finite_camera(monkeypatch):
     """A non-finite pixel_to_world entry - even in the column the shader multiplies by 0.0 - makes every ray NaN, and
     NaN roots pass hit_sphere's range tests (wgsl:214-222): such rays hit. No tile may then be treated as sky."""
