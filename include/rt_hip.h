@@ -82,8 +82,10 @@ int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames);
  * 518 400). RT_ERR_STATE while passes recorded by rt_compute are pending (call rt_sync first). Every call on a GPU
  * shares that GPU's array and rewrites what it uses, so two calls that overlap on one GPU (two contexts on different
  * streams) race; calls on one stream, or separated by rt_sync, do not. Not used here: staged (tile, frame) batches,
- * the cost-ordered tile queue and per-launch timing events, all of which need buffers of their own - expect a few per
- * cent less throughput than rt_render_frames on the same input. Asynchronous like rt_render_frames. */
+ * the cost-ordered tile queue, the per-tile candidate lists of scenes with more than 64 spheres and per-launch timing
+ * events, all of which need buffers of their own - expect a few per cent less throughput than rt_render_frames on
+ * small scenes and the round-1 loop shape (about 25 % less) on scenes of more than 64 spheres. Asynchronous like
+ * rt_render_frames. */
 int rt_render_frames_static(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames);
 
 /* queue.submit without the wait (app.rs:111): launches the passes rt_compute has recorded and returns; a launch
