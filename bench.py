@@ -235,7 +235,7 @@ def main():
 
     def flags_for(split):
         f = cfg["flags"]
-        if split == "frames" and world > 1:
+        if split == "frames" and use_dist:  # (RT_BENCH_FORCE_DIST=1 rehearses the N > 1 path with one rank)
             return f | R.RT_ACCUM_F32 | R.RT_COMBINE_SUM  # per-GPU frame sums, one reduce, x 1/n afterwards
         return f & ~R.RT_COMBINE_SUM
 
@@ -253,7 +253,7 @@ def main():
 
     m = run(args.math)
     extras = per_pass = other_split = None
-    if world > 1 and not args.no_extras:
+    if use_dist and not args.no_extras:
         other_split = run(args.math, "frames" if args.split == "tiles" else "tiles")
     if not args.no_extras and world == 1:
         extras = run("fast" if args.math == "strict" else "strict")
@@ -330,7 +330,7 @@ def main():
             "roofline": roof(m),
             "device": m["device"],
         }
-        if world > 1:
+        if use_dist:
             out["config"]["split"] = args.split
             out["config"]["parallelism"] = (f"{world} GPUs x interleaved 8x8 tiles of every frame, one RCCL reduce per render" if args.split == "tiles"
                                             else f"{world} GPUs x disjoint frame sets of the whole image, one RCCL reduce per render")
