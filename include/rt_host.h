@@ -60,7 +60,9 @@ uint32_t rth_app_time_bits(rth_app* app);
 /* The App's camera under the interactive controls (App::on_event -> Camera::key_press / zoom / look_at_pixel,
  * src/app.rs:50-91, src/resources/camera.rs:133-206) without winit: same key names and rules as rth_camera_*; each
  * call ends with scene_was_updated (camera.rs:283-288): current_frame = 0 and the new CameraRaw is uploaded.
- * rth_app_camera_get returns the 160 bytes the next pass will use. */
+ * rth_app_camera_get returns the 160 bytes the next pass will use. One call is one key pressed with only
+ * that key held (keys_held = {key}); several movement keys held at once in the reference equal one call per
+ * key here, because every translation goes through the same inverse rotation (camera.rs:149-170). */
 int rth_app_camera_key(rth_app* app, const char* key);
 int rth_app_camera_zoom(rth_app* app, float val);
 int rth_app_camera_look_at_pixel(rth_app* app, float off_x, float off_y);

@@ -64,7 +64,11 @@ class Camera {
   // headless forms of the interactive controls (no winit): each returns true when the scene changed,
   // in which case the caller does what scene_was_updated does (reset_render + upload, camera.rs:283-288)
   enum class Key { K, J, I, U, ArrowUp, ArrowDown, Backspace, W, S, D, A, Space, ShiftLeft };
-  bool key_press(Key key);                  // camera.rs:133-175 (one key, pressed and held)
+  // camera.rs:133-175 with keys_held = {key}: the reference applies the pressed key's setting change and then
+  // one translation per HELD movement key (all through the same inverse rotation, which does not depend on
+  // pos), so n keys held together equal n calls here, one per key, in W S D A Space ShiftLeft order. A key
+  // outside this enum changes nothing there and cannot be named here.
+  bool key_press(Key key);
   void zoom(float val);                     // camera.rs:193-197
   void look_at_pixel_from_center(float off_x, float off_y);  // camera.rs:200-206
   float speed = 0.05f;
