@@ -389,17 +389,27 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   // OWN-SPHERE DROP (SPLIT shape). A bounce ray starts ON the sphere it just hit, so phase 1 can never exclude that
   // sphere (its discriminant is ~ hb^2 >= 0) - and the exact test then rejects both roots almost always: they are ~ 0.
   // This proves the rejection from two dot products. Literal test of sphere `own` for the ray (o, d), wgsl:207-223:
-  //   oc = o - c (the three subtractions below ARE the literal ones), hb = dot(oc, d), x = dot(oc, oc),
-  //   c_l = fl(fl(sqrt(x))^2) - fl(r r), disc = fl(hb^2) - fl(a c_l), roots (-hb -+ sqrt(disc)) / a.
-  // Let hb >= 2^-30 (so hb^2 neither under- nor overflows; a, |o|, the scene are `tame`).
-  //  * c_l >= 0: fl(a c_l) >= 0, so disc <= fl(hb^2) and sqrt_rn(disc) <= sqrt_rn(fl(hb^2)) = hb (radix 2, no
-  //    underflow): -hb + sq <= 0, both roots <= 0 <= tmin: rejected (or disc < 0: rejected at once).
-  //  * c_l < 0, delta = -c_l: fl(len^2) >= x (1 - 2^-24)^3, hence delta <= (rr - x + 3.01 u x)(1 + u), u = 2^-24, and
-  //    delta <= dub (1 + 4u) for dub = fl(fl(rr - x) + 2^-20 x) below. sq <= sqrt(hb^2 + a delta)(1 + u)^2
-  //    <= (hb + a delta / (2 hb))(1 + u)^2, so root2 = fl(fl(-hb + sq) / a) <= [delta / (2 hb) + 2.1 u hb / a](1 + 6u).
-  //    With dub <= 2^-11 hb and hb <= 2048 a that is <= (2.45e-4 + 2.57e-4)(1 + 6u) < tmin = 1e-3: rejected; root1 < 0.
+  //   oc = o - c (the three subtractions below ARE the literal ones), hb = dot(oc, d), x = dot(oc, oc) (both computed
+  //   as the literal code computes them), c_l = fl(fl(fl(sqrt(x))^2) - fl(r r)), disc = fl(fl(hb^2) - fl(a c_l)),
+  //   roots fl(fl(-hb -+ sqrt_rn(disc)) / a). u = 2^-24.
+  // Let hb >= 2^-30 and the ray and scene be `tame` (a in [2^-21, 2^21]): hb <= |oc| |d| gives x >= 2^-81, and nothing
+  // below under- or overflows. root1 has a negative numerator: rejected. For root2:
+  //  * c_l >= 0: fl(a c_l) >= 0, so disc <= fl(hb^2) and sqrt_rn(disc) <= sqrt_rn(fl(hb^2)) = hb (radix 2): the
+  //    numerator -hb + sq is <= 0 and root2 <= 0 <= tmin: rejected (or disc < 0: rejected at once).
+  //  * c_l < 0, delta = -c_l: fl(len^2) >= x (1 - u)^3, so rr > x (1 - 3u): rr - x is exact (Sterbenz; or rr > 2x, and
+  //    then dub > x and the test below fails), T = (rr - x) + 4u x > 0.99 u x > 0, dub = fl(T) >= T (1 - u), and
+  //    delta <= (rr - x + 3.01 u x)(1 + u) <= T (1 + u) <= dub (1 + 4u). [So dub <= 0 proves c_l >= 0.]
+  //    sq <= sqrt(hb^2 + a delta)(1 + u)^2 <= (hb + a delta / (2 hb))(1 + 2.01u), hence
+  //    root2 <= [delta / (2 hb) + 2.1 u hb / a](1 + 6u), which is below tmin when
+  //        a dub (1 + 4u) + 4.2 u hb^2 < 2 hb a tmin / (1 + 6u).
+  //    The test evaluates  fl(fl(hb^2) 5u + fl(a dub)) <= fl(fl(hb a) * 2 tmin (1 - 2^-10)): five roundings of relative
+  //    size u each, against the slack of 2^-10 on the right and of 0.8 u hb^2 on the left.
   // So under `drop` hit_sphere returns false for `own` in the literal arithmetic (it has no side effect then), and the
-  // sphere leaves the candidate set. Grazing departures (hb tiny) and rays from huge spheres keep their exact test.
+  // sphere leaves the candidate set. With one inequality instead of separate limits on dub / hb and hb / a, rays that
+  // leave a BIG sphere at a grazing angle are covered too (the mirror ground of the default scene, r = 100: x ~ 10^4,
+  // dub ~ 2.4e-3 +- a few ulp of x, so every departure with hb >~ 2 - 1.2 degrees above the tangent plane - is dropped;
+  // the separate limits needed 11 degrees, and most of the visible ground is seen at less). What keeps its exact test
+  // is the last degree above the tangent plane, where the reference's own "shadow acne" lives.
   auto own_sphere_drop = [&]() __attribute__((always_inline)) -> bool {
     const bool has_own = own != 0xffffffffu;  // LIST: a primary ray that takes the general trace (its tile's list overflowed)
     const uint32_t oi = has_own ? own : 0u;
@@ -407,8 +417,10 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     const float ex = ox - so.x, ey = oy - so.y, ez = oz - so.z;
     const float x = STRICT ? dot_strict(ex, ey, ez, ex, ey, ez) : dot_fast(ex, ey, ez, ex, ey, ez);
     const float hbo = STRICT ? dot_strict(ex, ey, ez, dx, dy, dz) : dot_fast(ex, ey, ez, dx, dy, dz);
-    const float dub = __builtin_fmaf(x, 0x1p-20f, so.w - x);
-    return has_own && tame && hbo >= 0x1p-30f && dub <= 0x1p-11f * hbo && hbo <= 2048.0f * a_lit;
+    const float dub = __builtin_fmaf(x, 0x1p-22f, so.w - x);
+    const float lhs = __builtin_fmaf(hbo * hbo, 5.0f * 0x1p-24f, a_lit * dub);
+    const float rhs = (hbo * a_lit) * (2.0f * RT_RAY_TMIN * (1.0f - 0x1p-10f));
+    return has_own && tame && hbo >= 0x1p-30f && lhs <= rhs;
   };
 
   // [P] per-ray prelude; FILTER: also the per-ray terms of the phase-1 filter ("phase-1 filter"):

@@ -403,6 +403,25 @@ def test_phase1_filter_edge_scenes(name):
         _strict_equals_oracle(R, 64, 48, 3, 2, O.ACCUM_F32, spheres, mats, cam, counters)
 
 
+@pytest.mark.parametrize("radius,height,ground_index", [(100.0, 0.5, 0), (100.0, 0.02, 0), (1000.0, 0.5, 0), (30000.0, 1.0, 0),
+                                                        (100.0, 0.5, 1), (3.0, 0.01, 0)],
+                         ids=["r100", "r100_low_camera", "r1000", "r30000", "r100_diffuse", "r3_skimming"])
+def test_own_sphere_drop_on_big_spheres_at_grazing_angles(radius, height, ground_index):
+    """Bounce rays that leave a big sphere almost tangentially: the own-sphere drop (one inequality in hb, a and
+    r^2 - |o - c|^2) decides per ray whether the exact test of the sphere the ray starts on can be left out. A low
+    camera over a mirror (or diffuse) ground makes most reflections graze; the image stays the oracle's, acne included."""
+    R = _rt()
+    mats = scenes.make_materials(np.random.RandomState(9).random_sample((3, 4)).astype(np.float32))
+    centers = [(0.0, -radius - height, 0.0), (-1.0, 0.0, -2.0), (1.0, 0.0, -2.0), (0.0, 0.0, -2.0), (0.0, 0.5, -6.0)]
+    radii, idx = [radius, 0.5, 0.5, 0.5, 1.5], [0, 1, 2, 0, 1]
+    if ground_index == 1:  # the ground second: odd index = diffuse (wgsl:163)
+        centers[0], centers[1] = centers[1], centers[0]
+        radii[0], radii[1] = radii[1], radii[0]
+    spheres = scenes.make_spheres(centers, radii, idx)
+    cam = scenes.camera_raw(256, 160, spp=4, frames=2)
+    _strict_equals_oracle(R, 256, 160, 4, 2, O.ACCUM_F32, spheres, mats, cam, False)
+
+
 @pytest.mark.parametrize("flags", [0, O.ACCUM_F32], ids=["rgba8", "f32"])
 def test_checkpoint_file_resumes_bit_identically_and_rejects_mismatches(flags, tmp_path):
     """SURVEY 8f-4 through the host App: render 3 of 7 frames, save, load into a NEW App, finish; the image
