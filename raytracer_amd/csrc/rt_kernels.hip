@@ -249,16 +249,28 @@ __device__ __forceinline__ uint32_t phase1_missbits(const_f32x16_ptr sph_p1, uin
 #ifndef RT_PROFILE_SECTIONS
 #define RT_PROFILE_SECTIONS 0
 #endif
-#if RT_PROFILE_SECTIONS
+#if RT_PROFILE_SECTIONS == 1
 #define RT_PROF_BEGIN(i) prof_b##i = __builtin_amdgcn_s_memtime()
 #define RT_PROF_END(i) prof_acc##i += __builtin_amdgcn_s_memtime() - prof_b##i
-#define RT_PROF_BEGIN_IF(c, i) if (c) prof_b##i = __builtin_amdgcn_s_memtime()
-#define RT_PROF_END_IF(c, i) if (c) prof_acc##i += __builtin_amdgcn_s_memtime() - prof_b##i
+#define RT_PROF_LANES(i)
+#elif RT_PROFILE_SECTIONS == 2
+// lane occupancy instead of time: counters[i] += active lanes + (1 << 38) per execution of section i
+// (0 = [G0] new ray, 1 = [P1] prelude + phase 1, 2 = a rejection round, 3 = scatter, 4 = normalize, 5 = a trip of the walk)
+#define RT_PROF_BEGIN(i)
+#define RT_PROF_END(i)
+#define RT_PROF_LANES(i) do { const unsigned long long m_ = __ballot(true); /* the first active lane counts for the wave */ \
+    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u)) == 0u) \
+      atomicAdd(&prof_lds[i], (unsigned long long)__popcll(m_) + (1ull << 38)); } while (0)
+#elif RT_PROFILE_SECTIONS == 3
+// histogram of the candidates a ray brings to the walk: counters[0..4] = primary rays with 1, 2, 3, 4, 5+ candidates,
+// counters[8..11] = bounce rays with 1, 2, 3, 4+ (a bounce ray without candidates never reaches the walk)
+#define RT_PROF_BEGIN(i)
+#define RT_PROF_END(i)
+#define RT_PROF_LANES(i)
 #else
 #define RT_PROF_BEGIN(i)
 #define RT_PROF_END(i)
-#define RT_PROF_BEGIN_IF(c, i)
-#define RT_PROF_END_IF(c, i)
+#define RT_PROF_LANES(i)
 #endif
 
 // One frame of store_color / combine_pixel_cache_color (wgsl:96-112) on the accumulation pixel `acc`, shared
@@ -313,6 +325,9 @@ template <bool STRICT, bool COUNT, bool SMALL, bool SPLIT>
 // images of small scenes gain 1-2 % from the seventh wave (profiles/r1e_ab_waves.log), the 1024-sphere scene loses 3 %.
 #ifndef RT_SPLIT_WAVES
 #define RT_SPLIT_WAVES 7
+#endif
+#ifndef RT_WALK_MIN_LANES
+#define RT_WALK_MIN_LANES 6u   // MASK shape: lanes that must still hold candidates for a further trip of the walk in the same iteration
 #endif
 __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7) : RT_MIN_WAVES) void rt_path_kernel(const rt_kargs a) {
   static_assert(!SPLIT || !COUNT, "SPLIT needs the tile masks / lists, which counting launches do not use");
@@ -375,8 +390,15 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
 
 #if RT_PROFILE_SECTIONS
   unsigned long long prof_acc0 = 0, prof_acc1 = 0, prof_acc2 = 0, prof_acc3 = 0, prof_acc4 = 0, prof_acc5 = 0, prof_iters = 0, prof_p2_waves = 0, prof_p2_lanes = 0;
+  unsigned long long prof_live0 = 0, prof_live1 = 0, prof_live2 = 0, prof_live3 = 0;
   unsigned long long prof_b0 = 0, prof_b1 = 0, prof_b2 = 0, prof_b3 = 0, prof_b4 = 0, prof_b5 = 0;
   const unsigned long long prof_start = __builtin_amdgcn_s_memtime(), prof_rstart = __builtin_amdgcn_s_memrealtime();
+#endif
+#if RT_PROFILE_SECTIONS >= 2
+  __shared__ unsigned long long prof_lds[16];
+  if (threadIdx.x < 16u) prof_lds[threadIdx.x] = 0ull;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 #endif
   const uint32_t n_pad32 = (n_spheres + 3u) & ~3u;  // SPLIT (<= 32 spheres): the one block of the candidate walk
   // ---- the pieces of trace (wgsl:182-231) and of miss / scatter (wgsl:144-172); the two loop shapes below compose them ----
@@ -385,6 +407,11 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   bool tame = true;                  // the ray is inside the magnitude range of the phase-1 bound and of div_core
   uint32_t cand = 0;                 // spheres still to be tested exactly, in the bit layout of phase1_missbits
   uint32_t own = 0;                  // SPLIT: the sphere whose surface the current bounce ray starts on (its last hit)
+  // MASK shape: `closest` and `hit` of a candidate walk that continues in the next iteration. They share registers with
+  // values that are dead while a lane is in ST_TEST: gl2 (|q|^2 of an accepted point, live NEED_DIR -> GOT_DIR only) and
+  // own (consumed by the own-sphere drop at the end of [P1], set again by the next scatter).
+  float& w_closest = gl2;
+  uint32_t& w_hit = own;
 
   // OWN-SPHERE DROP (SPLIT shape). A bounce ray starts ON the sphere it just hit, so phase 1 can never exclude that
   // sphere (its discriminant is ~ hb^2 >= 0) - and the exact test then rejects both roots almost always: they are ~ 0.
@@ -498,9 +525,10 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   };
   auto walk = [&](uint32_t base, uint32_t cnt_pad, float& closest, int& hit, unsigned long long any_untame) __attribute__((always_inline)) {
     while (cand) {
-#if RT_PROFILE_SECTIONS
-      prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true));
+#if RT_PROFILE_SECTIONS == 1
+      prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true));  // (lane 0's view: its own trips)
 #endif
+      RT_PROF_LANES(5);
       const uint32_t lz = (uint32_t)__builtin_clz(cand);
       cand &= ~(0x80000000u >> lz);
       test_sphere(base + cnt_pad - 32u + lz, closest, hit, any_untame);
@@ -662,6 +690,12 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   for (;;) {
 #if RT_PROFILE_SECTIONS
     prof_iters++;
+#endif
+#if RT_PROFILE_SECTIONS == 2
+    {  // iterations by the number of lanes that hold a path (anything but dead / parked)
+      const uint32_t live = (uint32_t)__popcll(__ballot(state >= ST_READY));
+      if (live == 0u) prof_live0++; else if (live <= 16u) prof_live1++; else if (live <= 48u) prof_live2++; else prof_live3++;
+    }
 #endif
     // ================= [E] path end: next sample (cheap, every lane that finished a path) =================
     if (state == ST_PATH_DONE) {
@@ -954,6 +988,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       // the rounds, the walk and the scatter are each paid once per iteration for primary and bounce lanes together.
       RT_PROF_BEGIN(0);
       if (state == ST_NEW_RAY) {
+        RT_PROF_LANES(0);
         uint32_t s0, s1;
         RT_STEP(s0); RT_STEP(s1);
         start_ray(s0, s1);
@@ -961,17 +996,43 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         iters++;
         ray_prelude(std::integral_constant<bool, false>{}, unused);
         cand = tmask;
+        w_closest = RT_RAY_TMAX; w_hit = 0xffffffffu;
         state = ST_TEST;
       }
       RT_PROF_END(0);
       RT_PROF_BEGIN(3);
       if (state == ST_TEST) {
-        float closest = RT_RAY_TMAX;
-        int hit = -1;
-        walk(0u, n_pad32, closest, hit, __ballot(!tame));
+        // The walk's `closest` and `hit` live in w_closest / w_hit across iterations (two registers that are free while
+        // a lane is in ST_TEST, see their declaration): after the first trip, a further trip runs only while at least
+        // RT_WALK_MIN_LANES lanes still hold candidates - a trip costs the wave ~85 instructions whoever takes part, and
+        // the few rays with a second or third candidate (a third of the bounce rays, hardly any primary ray since the
+        // occlusion drop of the tile masks) would otherwise make every iteration pay two or three of them. Such a lane
+        // keeps ST_TEST and takes its next candidate in the next iteration's first trip, which runs anyway: one loop
+        // iteration more for that path, in the same ascending sphere order (so with the same result).
+        float closest = w_closest;
+        int hit = (int)w_hit;
+#if RT_PROFILE_SECTIONS == 3
+        if (hit < 0 && closest == RT_RAY_TMAX) {
+          const uint32_t pc = (uint32_t)__popc(cand);
+          if (pc) atomicAdd(&prof_lds[depth == 0u ? (pc > 5u ? 5u : pc) - 1u : 8u + (pc > 4u ? 4u : pc) - 1u], 1ull);
+        }
+#endif
+        const unsigned long long any_untame = __ballot(!tame);
+        for (;;) {
+          if (cand) {
+            RT_PROF_LANES(5);
+            const uint32_t lz = (uint32_t)__builtin_clz(cand);
+            cand &= ~(0x80000000u >> lz);
+            test_sphere(n_pad32 - 32u + lz, closest, hit, any_untame);
+          }
+          const uint32_t left = (uint32_t)__popcll(__ballot(cand != 0u));
+          if (left < RT_WALK_MIN_LANES) break;  // (also: nothing left)
+        }
         RT_PROF_END(3);
         RT_PROF_BEGIN(4);
-        if (hit < 0) shade_miss(); else shade_hit(closest, hit);
+        if (cand != 0u) { w_closest = closest; w_hit = (uint32_t)hit; }
+        else if (hit < 0) shade_miss();
+        else { RT_PROF_LANES(3); shade_hit(closest, hit); }
         RT_PROF_END(4);
         RT_PROF_BEGIN(3);
       }
@@ -979,14 +1040,16 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       RT_PROF_BEGIN(0);
       for (uint32_t round = 0; round < a.reject_tries && __ballot(state == ST_NEED_DIR) != 0ull; ++round) {
         if (state == ST_NEED_DIR) {
+          RT_PROF_LANES(2);
           uint32_t s0, s1, s2;
           RT_STEP(s0); RT_STEP(s1); RT_STEP(s2);
           try_direction(s0, s1, s2);
         }
       }
-      if (state == ST_GOT_DIR) finish_direction();
+      if (state == ST_GOT_DIR) { RT_PROF_LANES(4); finish_direction(); }
       RT_PROF_END(0);
       if (state == ST_READY) {
+        RT_PROF_LANES(1);
         RT_PROF_BEGIN(1);
         iters++;
         p1_ray p1q;
@@ -995,6 +1058,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         RT_PROF_BEGIN(2);
         const uint32_t missbits = phase1_missbits<CULL>(sph_p1, 0u, n_pad32, p1q);
         cand = (~missbits | (tame ? 0u : 0xffffffffu)) & valid32 & ~(own_sphere_drop() ? 1u << (n_pad32 - 1u - own) : 0u);
+        w_closest = RT_RAY_TMAX; w_hit = 0xffffffffu;  // (own is dead from here on: w_hit shares its register)
         state = ST_TEST;
         if (cand == 0u) shade_miss();
         RT_PROF_END(2);
@@ -1048,14 +1112,28 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   if (lane_id() == 0u) {
     const unsigned long long life = __builtin_amdgcn_s_memtime() - prof_start;
     const unsigned long long rlife = __builtin_amdgcn_s_memrealtime() - prof_rstart;  // 100 MHz
+#if RT_PROFILE_SECTIONS >= 2
+    const unsigned long long pv[8] = {prof_lds[0], prof_lds[1], prof_lds[2], prof_lds[3], prof_lds[4], life, prof_iters, rlife};
+    prof_p2_lanes = prof_lds[5] & ((1ull << 38) - 1ull); prof_p2_waves = prof_lds[5] >> 38;
+#else
     const unsigned long long pv[8] = {prof_acc0, prof_acc1, prof_acc2, prof_acc3, prof_acc4, life, prof_iters, rlife};
+#endif
     for (int i = 0; i < 8; ++i) atomicAdd(&ca->counters[i], pv[i]);
     // launch shape: [8] = ~min start, [9] = max end, [10] = sum of starts, [11] = sum of ends (100 MHz ticks),
     // [12], [13] = lane- and wave-iterations of the phase-2 candidate loop
+#if RT_PROFILE_SECTIONS == 3
+    for (int i = 0; i < 4; ++i) atomicAdd(&ca->counters[8 + i], prof_lds[8 + i]);
+#elif RT_PROFILE_SECTIONS == 2
+    atomicAdd(&ca->counters[8], prof_live0);   // iterations with no / 1-16 / 17-48 / 49-64 lanes holding a path
+    atomicAdd(&ca->counters[9], prof_live1);
+    atomicAdd(&ca->counters[10], prof_live2);
+    atomicAdd(&ca->counters[11], prof_live3);
+#else
     atomicMax(&ca->counters[8], ~prof_rstart);
     atomicMax(&ca->counters[9], prof_rstart + rlife);
     atomicAdd(&ca->counters[10], prof_rstart & 0xffffffffull);
     atomicAdd(&ca->counters[11], (prof_rstart + rlife) & 0xffffffffull);
+#endif
     atomicAdd(&ca->counters[12], prof_p2_lanes);  // candidate walk: lane-iterations
     atomicAdd(&ca->counters[13], prof_p2_waves);  // candidate walk: wave-iterations
   }
@@ -1156,32 +1234,70 @@ __global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, ui
     mask = 0u;
     n_list = 0u;
     const double sin_t = rho / ndc, cos_t = sqrt(1.0 - sin_t * sin_t);
+    // candidates that survive the miss tests, with the lower bound of their accepted roots (OCCLUSION, below)
+    constexpr uint32_t MAXC = 64u;
+    uint16_t cidx[MAXC];
+    double clow[MAXC];
+    uint32_t nc = 0;
+    bool overflow = false;
+    double up_min = 1.0e300;  // smallest upper bound of a certain hit's root (as a distance) among the tile's spheres
     for (uint32_t i = 0; i < a.n_spheres; ++i) {
       const rt_f32x4 sp = a.sph_shade[i];
-      const double c[3] = {sp.x, sp.y, sp.z}, r2 = (double)sp.w * sp.w;
+      const double c[3] = {sp.x, sp.y, sp.z}, r = fabs((double)sp.w), r2 = r * r;  // (hit_sphere sees r only as r r)
       const double v[3] = {c[0] - o[0], c[1] - o[1], c[2] - o[2]};
       const double L2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
       const double m = 0x1p-12 * (oo + c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + r2);
       bool miss = false;
+      double low = -1.0e300;
       if (L2 - r2 > m) {
-        const double cpsi = (v[0] * dc[0] + v[1] * dc[1] + v[2] * dc[2]) / (sqrt(L2) * ndc);
-        const double ac = fmin(fabs(cpsi), 1.0), sp1 = sqrt(1.0 - ac * ac);
+        const double L = sqrt(L2);
+        const double cpsi = fmax(-1.0, fmin(1.0, (v[0] * dc[0] + v[1] * dc[1] + v[2] * dc[2]) / (L * ndc)));
+        const double ac = fabs(cpsi), sp1 = sqrt(1.0 - ac * ac);
         const double sdiff = sp1 * cos_t - ac * sin_t;  // sin(min(psi, pi - psi) - theta)
         const bool clear = sdiff > 0.0 && L2 * sdiff * sdiff > (r2 + m) * (1.0 + 0x1p-20);
         const bool behind = cpsi * cos_t + sp1 * sin_t < -0x1p-8;  // cos(psi - theta)
         miss = clear || behind;
-      }
-      if (!miss) {
-        if (per_sphere) {
-          mask |= 1u << (cnt_pad - 1u - i);
-        } else {
-          mask = everything;
-          if (!list) break;                      // only "sky tile or not" is wanted
-          if (n_list >= 15u) { n_list = 0xffffu; break; }
-          list[1u + n_list++] = (uint16_t)i;     // ascending index: the order hit_sphere's tie rule needs
+        if (!miss) {
+          // the rays of the tile meet the line to the centre under angles in [max(0, psi - theta), psi + theta]
+          const double smin = cpsi > 0.0 && sdiff <= 0.0 ? 0.0 : sp1 * cos_t - cpsi * sin_t;
+          const double cmin = cpsi > 0.0 && sdiff <= 0.0 ? 1.0 : cpsi * cos_t + sp1 * sin_t;
+          const double sloc = sqrt(L2 + r2);
+          if (cmin > 0.0) low = (L * cmin - sqrt(fmax(0.0, r2 - L2 * smin * smin)) - 0x1p-7 * sloc) * (1.0 - 0x1p-20);
+          const double smax = sp1 * cos_t + cpsi * sin_t, cmax = cpsi * cos_t - sp1 * sin_t;
+          const double inner = r2 - L2 * smax * smax;  // r^2 - (distance of the worst line from the centre)^2
+          const double ea = 0x1p-6 * r + 0x1p-19 * L;
+          if (cpsi > 0.0 && cmax > 0.0 && inner >= 0x1p-12 * (L2 + r2) && (L - r) - ea > RT_RAY_TMIN * (ndc + rho) * (1.0 + 0x1p-10)) {
+            const double up = (L * cmax - sqrt(inner) + ea) * (1.0 + 0x1p-20);
+            up_min = fmin(up_min, up);
+          }
         }
       }
+      if (!miss) {
+        if (!per_sphere && !list) { mask = everything; break; }  // only "sky tile or not" is wanted
+        if (nc < MAXC) { cidx[nc] = (uint16_t)i; clow[nc] = low; ++nc; } else overflow = true;
+      }
     }
+    // OCCLUSION. hit_sphere's loop ends with the smallest accepted root and, among equal ones, the lowest index
+    // (every sphere has ONE root it can be accepted with - its smallest one above tmin - whatever `closest` is when
+    // it is tested). So a sphere B may be left out when some sphere A of the tile is hit by EVERY primary ray of the
+    // tile with a root strictly below every root B can be accepted with. In distances along the ray (root x |d|):
+    //   A: all lines of the cone pass the centre within sqrt(r^2 - 2^-12 (L^2 + r^2)); the literal discriminant is
+    //      within 2^-18 a (L^2 + r^2) of the exact one (oc = o - c is ONE rounding per component, so every error is
+    //      relative to |oc| and r), hence positive and known to 2^-6; the accepted root is the first one (the
+    //      origin is outside by more than tmin |d|), at most l_A(psi + theta) + 2^-6 r + 2^-19 L = `up`;
+    //   B: whatever its conditioning, a literal root is at least l_B(max(0, psi - theta)) - 2^-7 sqrt(L^2 + r^2) =
+    //      `low` (l(phi) = L cos phi - sqrt(r^2 - L^2 sin^2 phi), increasing in phi; a literal hit on an exact
+    //      miss lies within that margin of the tangent length).
+    // up_min < low(B) drops B; the sphere that attains up_min has low < up and stays.
+    uint32_t kept = 0;
+    for (uint32_t q = 0; q < nc; ++q) {
+      if (up_min < clow[q]) continue;
+      if (per_sphere) mask |= 1u << (cnt_pad - 1u - cidx[q]);
+      else { mask = everything; if (kept < 15u) list[1u + kept] = cidx[q]; }  // ascending index: the order the tie rule needs
+      ++kept;
+    }
+    if (overflow) mask = everything;  // more candidates than clow[] holds (big scenes only): no list, no sky tile
+    if (!per_sphere && list) n_list = overflow || kept > 15u ? 0xffffu : kept;
   }
   masks[j] = mask;
   if (list) list[0] = (uint16_t)n_list;

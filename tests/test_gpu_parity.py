@@ -422,6 +422,40 @@ def test_own_sphere_drop_on_big_spheres_at_grazing_angles(radius, height, ground
     _strict_equals_oracle(R, 256, 160, 4, 2, O.ACCUM_F32, spheres, mats, cam, False)
 
 
+@pytest.mark.parametrize("case", ["stacked", "nested_and_coincident", "bunch32_near", "bunch300_lists", "negative_and_zero_radii"])
+def test_occlusion_drop_of_the_tile_masks_keeps_the_nearest_sphere(case, monkeypatch):
+    """rt_tile_masks_kernel leaves a sphere out of a tile's candidates when another sphere is certainly hit in front
+    of it by every primary ray of the tile. Spheres behind each other with small and zero depth gaps, one inside the
+    other, the same sphere twice (the tie rule), dense bunches seen from close by, and the candidate lists of a
+    300-sphere scene: images and RNG states stay the oracle's, and equal the render without tile masks."""
+    R = _rt()
+    rs = np.random.RandomState(77)
+    mats = scenes.make_materials(rs.random_sample((3, 4)).astype(np.float32))
+    camkw = {}
+    if case == "stacked":
+        spheres = scenes.make_spheres([(0, 0, -3), (0.02, 0, -3.05), (0, 0.1, -3.5), (0.3, 0, -6), (-0.5, 0.2, -2.2), (0, 0, -40)],
+                                      [1.0, 1.0, 1.2, 2.0, 0.3, 30.0], [0, 1, 2, 0, 1, 2])
+    elif case == "nested_and_coincident":
+        spheres = scenes.make_spheres([(0, 0, -4), (0, 0, -4), (0, 0, -4), (0.5, 0, -4), (0, 0, -4.001)],
+                                      [1.0, 1.0, 0.5, 1.0, 1.0], [1, 0, 2, 0, 1])
+    elif case == "bunch32_near":
+        spheres, mats = scenes.random_bunch(32, 3, 11)
+        camkw = dict(pos=(0.5, 0.2, -1.0), look=(0.1, -0.1, -1.0), fov=0.45)
+    elif case == "bunch300_lists":
+        spheres, mats = scenes.random_bunch(300, 3, 12)
+        camkw = dict(fov=0.3)
+    else:
+        spheres = scenes.make_spheres([(0, 0, -5), (0.2, 0, -9), (0, 0.5, -3), (-1, 0, -7)], [-2.0, 3.0, 0.0, -1.5], [0, 1, 2, 1])
+    W, H = 320, 192
+    cam = scenes.camera_raw(W, H, spp=2, frames=2, **camkw)
+    _strict_equals_oracle(R, W, H, 2, 2, O.ACCUM_F32, spheres, mats, cam, False)
+    monkeypatch.setenv("RT_SKY_TILES", "1")
+    on = _render_state(R, W, H, O.ACCUM_F32 | 0x8, spheres, mats, cam, 2, False)
+    monkeypatch.setenv("RT_SKY_TILES", "0")
+    off = _render_state(R, W, H, O.ACCUM_F32 | 0x8, spheres, mats, cam, 2, False)
+    assert np.array_equal(on[1], off[1]) and np.array_equal(on[2], off[2])  # fast arithmetic: masks change no bit either
+
+
 @pytest.mark.parametrize("flags", [0, O.ACCUM_F32], ids=["rgba8", "f32"])
 def test_checkpoint_file_resumes_bit_identically_and_rejects_mismatches(flags, tmp_path):
     """SURVEY 8f-4 through the host App: render 3 of 7 frames, save, load into a NEW App, finish; the image

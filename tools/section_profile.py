@@ -20,6 +20,23 @@ def run(name, W, H, spp, scene, shade, math):
         rt.set_camera(cam); rt.set_time(int(tb[i])); rt.compute(); rt.sync()
     c = rt.counters()
     life = c["S"]; iters = c["Sm"]
+    if os.environ.get("SECTION_LANES") == "hist":  # -DRT_PROFILE_SECTIONS=3: candidates per ray at the walk
+        prim = [c[k] for k in ("T", "D", "H", "R", "M")]; bounce = [c[k] for k in ("Sd", "N", "P", "rand_calls")]
+        print(f"{name} {'fast' if math else 'strict'}: primary rays with 1, 2, 3, 4, 5+ candidates: " + ", ".join(f"{100.0 * v / max(sum(prim), 1):.1f} %" for v in prim)
+              + f" (mean {sum((i + 1) * v for i, v in enumerate(prim)) / max(sum(prim), 1):.2f}); bounce rays with 1, 2, 3, 4+: "
+              + ", ".join(f"{100.0 * v / max(sum(bounce), 1):.1f} %" for v in bounce) + f"; primary : bounce = {sum(prim) / max(sum(bounce), 1):.2f}")
+        rt.close()
+        return
+    if os.environ.get("SECTION_LANES"):  # library built with -DRT_PROFILE_SECTIONS=2: lane occupancy per section
+        occ = rt.occupancy()
+        print(f"{name} {'fast' if math else 'strict'}: {iters} wave-iterations")
+        for label, key in (("[G0] new ray", "T"), ("[P1] prelude + phase 1", "D"), ("rejection round", "H"), ("scatter", "R"), ("normalize", "M")):
+            lanes, execs = c[key] & ((1 << 38) - 1), c[key] >> 38
+            print(f"   {label:24s} {execs / iters:5.2f} executions per iteration, {lanes / max(execs, 1):5.1f} of 64 lanes")
+        print(f"   {'candidate walk trip':24s} {occ['slots_reject'] / iters:5.2f} executions per iteration, {occ['slots_trace'] / max(occ['slots_reject'], 1):5.1f} of 64 lanes")
+        print("   iterations by lanes holding a path: none %.1f %%, 1-16 %.1f %%, 17-48 %.1f %%, 49-64 %.1f %%" % tuple(100.0 * c[k] / iters for k in ("Sd", "N", "P", "rand_calls")))
+        rt.close()
+        return
     parts = [("[G] draws", c["T"]), ("trace prelude", c["D"]), ("phase 1", c["H"]), ("phase 2", c["R"]), ("shade", c["M"])]
     other = life - sum(v for _, v in parts)
     print(f"{name} {'fast' if math else 'strict'}: {iters} wave-iterations, {life/iters:.0f} wave-cycles per iteration, "
@@ -45,3 +62,4 @@ if __name__ == "__main__":
         run("C3", 3840, 2160, 64, scenes.random_bunch(20, 3, 3), R.RT_SHADE_CHECKER, math)
         run("C4", 1920, 1080, 4, scenes.random_bunch(1024, 16, 4), 0, math)
         run("C2", 1920, 1080, 16, scenes.default_scene(1), 0, math)
+        run("4K default scene", 3840, 2160, 64, scenes.default_scene(1), 0, math)
