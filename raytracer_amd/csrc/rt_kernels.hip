@@ -250,8 +250,13 @@ __device__ __forceinline__ uint32_t phase1_missbits(const_f32x16_ptr sph_p1, uin
 #define RT_PROFILE_SECTIONS 0
 #endif
 #if RT_PROFILE_SECTIONS == 1
-#define RT_PROF_BEGIN(i) prof_b##i = __builtin_amdgcn_s_memtime()
-#define RT_PROF_END(i) prof_acc##i += __builtin_amdgcn_s_memtime() - prof_b##i
+// -DRT_PROFILE_ONLY=i times section i alone: two clock reads per iteration instead of twenty (with all five sections
+// timed at once the reads themselves are a quarter of the wave's time, most of it booked on the untimed remainder)
+#ifndef RT_PROFILE_ONLY
+#define RT_PROFILE_ONLY -1
+#endif
+#define RT_PROF_BEGIN(i) do { if (RT_PROFILE_ONLY < 0 || RT_PROFILE_ONLY == i) prof_b##i = __builtin_amdgcn_s_memtime(); } while (0)
+#define RT_PROF_END(i) do { if (RT_PROFILE_ONLY < 0 || RT_PROFILE_ONLY == i) prof_acc##i += __builtin_amdgcn_s_memtime() - prof_b##i; } while (0)
 #define RT_PROF_LANES(i)
 #elif RT_PROFILE_SECTIONS == 2
 // lane occupancy instead of time: counters[i] += active lanes + (1 << 38) per execution of section i
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   constexpr bool LIST = SPLIT && !SMALL;  // > 64 spheres: the tile's candidates are a short list; primary and general trace
   // behind cull: strict small-scene launches (fewer exact tests), and every SPLIT launch (there a bounce ray without
   // candidates is finished on the spot, so candidates that only fall to the exact test cost a loop iteration)
+  constexpr bool QUEUE = STRICT && !SMALL && !COUNT;  // the general trace collects a ray's candidates over all blocks before the exact tests
   constexpr bool CULL = SMALL && (STRICT || SPLIT);  // (the 1024-sphere scene loses 2 % with it: one more instruction per sphere)
   // The lane index is recomputed where the cold code needs it (two v_mbcnt behind a compiler barrier) instead of
   // living in a register across the hot loop: at 72 registers that one value was the last spill.
@@ -657,6 +663,27 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
       const bool own_drop = LIST ? own_sphere_drop() : false;
       if (COUNT) { c_R++; c_T += n_spheres; }
+      // CANDIDATE QUEUE (strict launches on scenes of more than RT_SMALL_MAX spheres). A ray of the 1024-sphere scene has
+      // 1.4 candidates in all, spread over 32 blocks: walking them block by block ran 18 trips of the exact test per
+      // loop iteration with 2.5 of 64 lanes in each (profiles/r2b_section_lanes.log) - a fifth of the kernel's
+      // instructions. Instead a lane queues the sphere indices phase 1 leaves it (four 16-bit entries in a register
+      // pair, oldest on top) and the wave tests them when the trace is through all blocks - or earlier, when some
+      // lane's queue is full: 3-4 trips with a third of the lanes in each. Every lane still meets its candidates in
+      // ascending sphere order (hit_sphere's tie rule). In fast arithmetic a trip is 25 instructions and queueing would
+      // cost what it saves.
+      unsigned long long queue = 0ull;
+      uint32_t qn = 0;
+      const bool use_queue = n_spheres <= 0xffffu;
+      auto drain = [&]() __attribute__((always_inline)) {
+        while (qn) {
+#if RT_PROFILE_SECTIONS == 1
+          prof_p2_waves++; prof_p2_lanes += (unsigned long long)__popcll(__ballot(true));
+#endif
+          RT_PROF_LANES(5);
+          qn--;
+          test_sphere((uint32_t)(queue >> (16u * qn)) & 0xffffu, closest, hit, any_untame);
+        }
+      };
       RT_PROF_END(1);
       for (uint32_t base = 0; base < n_spheres; base += 32u) {
         const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
@@ -678,7 +705,34 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           const uint32_t rel = own - base;
           if (own_drop && rel < cnt) cand &= ~(1u << (cnt_pad - 1u - rel));
         }
-        walk(base, cnt_pad, closest, hit, any_untame);
+        if (QUEUE && use_queue) {
+          // every lane meets its candidates in ascending order: queued ones are older than what is still in `cand`,
+          // and the queues are empty when a block is walked directly
+          auto push = [&]() __attribute__((always_inline)) {
+            while (cand != 0u && qn < 4u) {
+              const uint32_t lz = (uint32_t)__builtin_clz(cand);
+              cand &= ~(0x80000000u >> lz);
+              queue = (queue << 16) | (unsigned long long)(base + cnt_pad - 32u + lz);  // newest entry lowest
+              qn++;
+            }
+          };
+          push();
+          if (__ballot(cand != 0u)) {  // some lane's queue is full: everyone tests what is queued, then the rest of this block
+            drain();
+            push();
+            if (__ballot(cand != 0u)) {  // a block with more than four candidates for a lane (untamed rays: every sphere)
+              drain();
+              walk(base, cnt_pad, closest, hit, any_untame);
+            }
+          }
+        } else {
+          walk(base, cnt_pad, closest, hit, any_untame);
+        }
+        RT_PROF_END(3);
+      }
+      if (QUEUE && use_queue) {
+        RT_PROF_BEGIN(3);
+        drain();
         RT_PROF_END(3);
       }
       RT_PROF_BEGIN(4);
@@ -1234,49 +1288,34 @@ __global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, ui
     mask = 0u;
     n_list = 0u;
     const double sin_t = rho / ndc, cos_t = sqrt(1.0 - sin_t * sin_t);
-    // candidates that survive the miss tests, with the lower bound of their accepted roots (OCCLUSION, below)
-    constexpr uint32_t MAXC = 64u;
-    uint16_t cidx[MAXC];
-    double clow[MAXC];
-    uint32_t nc = 0;
-    bool overflow = false;
-    double up_min = 1.0e300;  // smallest upper bound of a certain hit's root (as a distance) among the tile's spheres
-    for (uint32_t i = 0; i < a.n_spheres; ++i) {
+    // Per sphere: certain miss?; `low` = lower bound of every root it can be accepted with and `up` = upper bound of
+    // the root of a CERTAIN hit, both as distances along the ray (OCCLUSION, below; up = +inf when the hit is not certain)
+    auto classify = [&](uint32_t i, double& low, double& up) -> bool {
       const rt_f32x4 sp = a.sph_shade[i];
       const double c[3] = {sp.x, sp.y, sp.z}, r = fabs((double)sp.w), r2 = r * r;  // (hit_sphere sees r only as r r)
       const double v[3] = {c[0] - o[0], c[1] - o[1], c[2] - o[2]};
       const double L2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
       const double m = 0x1p-12 * (oo + c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + r2);
-      bool miss = false;
-      double low = -1.0e300;
-      if (L2 - r2 > m) {
-        const double L = sqrt(L2);
-        const double cpsi = fmax(-1.0, fmin(1.0, (v[0] * dc[0] + v[1] * dc[1] + v[2] * dc[2]) / (L * ndc)));
-        const double ac = fabs(cpsi), sp1 = sqrt(1.0 - ac * ac);
-        const double sdiff = sp1 * cos_t - ac * sin_t;  // sin(min(psi, pi - psi) - theta)
-        const bool clear = sdiff > 0.0 && L2 * sdiff * sdiff > (r2 + m) * (1.0 + 0x1p-20);
-        const bool behind = cpsi * cos_t + sp1 * sin_t < -0x1p-8;  // cos(psi - theta)
-        miss = clear || behind;
-        if (!miss) {
-          // the rays of the tile meet the line to the centre under angles in [max(0, psi - theta), psi + theta]
-          const double smin = cpsi > 0.0 && sdiff <= 0.0 ? 0.0 : sp1 * cos_t - cpsi * sin_t;
-          const double cmin = cpsi > 0.0 && sdiff <= 0.0 ? 1.0 : cpsi * cos_t + sp1 * sin_t;
-          const double sloc = sqrt(L2 + r2);
-          if (cmin > 0.0) low = (L * cmin - sqrt(fmax(0.0, r2 - L2 * smin * smin)) - 0x1p-7 * sloc) * (1.0 - 0x1p-20);
-          const double smax = sp1 * cos_t + cpsi * sin_t, cmax = cpsi * cos_t - sp1 * sin_t;
-          const double inner = r2 - L2 * smax * smax;  // r^2 - (distance of the worst line from the centre)^2
-          const double ea = 0x1p-6 * r + 0x1p-19 * L;
-          if (cpsi > 0.0 && cmax > 0.0 && inner >= 0x1p-12 * (L2 + r2) && (L - r) - ea > RT_RAY_TMIN * (ndc + rho) * (1.0 + 0x1p-10)) {
-            const double up = (L * cmax - sqrt(inner) + ea) * (1.0 + 0x1p-20);
-            up_min = fmin(up_min, up);
-          }
-        }
-      }
-      if (!miss) {
-        if (!per_sphere && !list) { mask = everything; break; }  // only "sky tile or not" is wanted
-        if (nc < MAXC) { cidx[nc] = (uint16_t)i; clow[nc] = low; ++nc; } else overflow = true;
-      }
-    }
+      low = -1.0e300; up = 1.0e300;
+      if (!(L2 - r2 > m)) return false;
+      const double L = sqrt(L2);
+      const double cpsi = fmax(-1.0, fmin(1.0, (v[0] * dc[0] + v[1] * dc[1] + v[2] * dc[2]) / (L * ndc)));
+      const double ac = fabs(cpsi), sp1 = sqrt(1.0 - ac * ac);
+      const double sdiff = sp1 * cos_t - ac * sin_t;  // sin(min(psi, pi - psi) - theta)
+      const bool clear = sdiff > 0.0 && L2 * sdiff * sdiff > (r2 + m) * (1.0 + 0x1p-20);
+      const bool behind = cpsi * cos_t + sp1 * sin_t < -0x1p-8;  // cos(psi - theta)
+      if (clear || behind) return true;
+      // the rays of the tile meet the line to the centre under angles in [max(0, psi - theta), psi + theta]
+      const double smin = cpsi > 0.0 && sdiff <= 0.0 ? 0.0 : sp1 * cos_t - cpsi * sin_t;
+      const double cmin = cpsi > 0.0 && sdiff <= 0.0 ? 1.0 : cpsi * cos_t + sp1 * sin_t;
+      if (cmin > 0.0) low = (L * cmin - sqrt(fmax(0.0, r2 - L2 * smin * smin)) - 0x1p-7 * sqrt(L2 + r2)) * (1.0 - 0x1p-20);
+      const double smax = sp1 * cos_t + cpsi * sin_t, cmax = cpsi * cos_t - sp1 * sin_t;
+      const double inner = r2 - L2 * smax * smax;  // r^2 - (distance of the cone's worst line from the centre)^2
+      const double ea = 0x1p-6 * r + 0x1p-19 * L;
+      if (cpsi > 0.0 && cmax > 0.0 && inner >= 0x1p-12 * (L2 + r2) && (L - r) - ea > RT_RAY_TMIN * (ndc + rho) * (1.0 + 0x1p-10))
+        up = (L * cmax - sqrt(inner) + ea) * (1.0 + 0x1p-20);
+      return false;
+    };
     // OCCLUSION. hit_sphere's loop ends with the smallest accepted root and, among equal ones, the lowest index
     // (every sphere has ONE root it can be accepted with - its smallest one above tmin - whatever `closest` is when
     // it is tested). So a sphere B may be left out when some sphere A of the tile is hit by EVERY primary ray of the
@@ -1288,16 +1327,29 @@ __global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, ui
     //   B: whatever its conditioning, a literal root is at least l_B(max(0, psi - theta)) - 2^-7 sqrt(L^2 + r^2) =
     //      `low` (l(phi) = L cos phi - sqrt(r^2 - L^2 sin^2 phi), increasing in phi; a literal hit on an exact
     //      miss lies within that margin of the tangent length).
-    // up_min < low(B) drops B; the sphere that attains up_min has low < up and stays.
-    uint32_t kept = 0;
-    for (uint32_t q = 0; q < nc; ++q) {
-      if (up_min < clow[q]) continue;
-      if (per_sphere) mask |= 1u << (cnt_pad - 1u - cidx[q]);
-      else { mask = everything; if (kept < 15u) list[1u + kept] = cidx[q]; }  // ascending index: the order the tie rule needs
-      ++kept;
+    // up_min < low(B) drops B; the sphere that attains up_min has low < up and stays. Two passes over the spheres
+    // (first up_min, then the candidates) instead of a per-thread array: the kernel keeps no scratch memory.
+    double up_min = 1.0e300;
+    bool any = false;
+    for (uint32_t i = 0; i < a.n_spheres; ++i) {
+      double low, up;
+      if (classify(i, low, up)) continue;
+      any = true;
+      if (!per_sphere && !list) break;  // only "sky tile or not" is wanted
+      up_min = fmin(up_min, up);
     }
-    if (overflow) mask = everything;  // more candidates than clow[] holds (big scenes only): no list, no sky tile
-    if (!per_sphere && list) n_list = overflow || kept > 15u ? 0xffffu : kept;
+    if (any && !per_sphere) mask = everything;
+    if (any && (per_sphere || list)) {
+      uint32_t kept = 0;
+      for (uint32_t i = 0; i < a.n_spheres; ++i) {
+        double low, up;
+        if (classify(i, low, up) || up_min < low) continue;
+        if (per_sphere) mask |= 1u << (cnt_pad - 1u - i);
+        else if (kept < 15u) list[1u + kept] = (uint16_t)i;  // ascending index: the order hit_sphere's tie rule needs
+        ++kept;
+      }
+      if (!per_sphere) n_list = kept > 15u ? 0xffffu : kept;
+    }
   }
   masks[j] = mask;
   if (list) list[0] = (uint16_t)n_list;

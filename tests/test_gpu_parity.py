@@ -882,6 +882,34 @@ def test_list_shape_candidate_lists_short_long_and_overflowing(n, W, H, fov, mon
             rt.close()
 
 
+@pytest.mark.parametrize("case", ["row_of_100", "two_clumps_of_40", "huge_shell_around_200"])
+def test_candidate_queue_of_the_general_trace_fills_and_overflows(case, monkeypatch):
+    """Strict launches on scenes of more than 64 spheres queue a ray's candidates (four per lane) across the 32-sphere
+    blocks and test them afterwards. Rays that pierce many spheres - a row of spheres behind each other, clumps that
+    put more than four candidates into one block, a camera inside a huge sphere (every ray hits it, from inside) -
+    fill the queue, drain it early and fall back to the block-by-block walk: the image stays the oracle's, with
+    tile lists and without (RT_SPLIT=0: primary rays take the general trace too)."""
+    R = _rt()
+    rs = np.random.RandomState(91)
+    mats = scenes.make_materials(rs.random_sample((3, 4)).astype(np.float32))
+    if case == "row_of_100":
+        centers = [(0.05 * (k % 3), 0.03 * (k % 5), -3.0 - 0.45 * k) for k in range(100)]
+        radii = [1.0 + 0.002 * k for k in range(100)]
+    elif case == "two_clumps_of_40":
+        centers = [tuple(rs.normal(0, 0.15, 3) + np.array([-0.6 if k < 40 else 0.6, 0.0, -4.0])) for k in range(80)]
+        radii = [0.5] * 80
+    else:
+        centers = [(0.0, 0.0, 0.0)] + [tuple((rs.random_sample(3) * 2 - 1) * 6 + np.array([0, 0, -9.0])) for _ in range(199)]
+        radii = [40.0] + [0.7] * 199
+    n = len(radii)
+    spheres = scenes.make_spheres(centers, radii, rs.randint(0, 3, size=n))
+    W, H = 192, 128
+    cam = scenes.camera_raw(W, H, spp=2, frames=2)
+    _strict_equals_oracle(R, W, H, 2, 2, O.ACCUM_F32, spheres, mats, cam, False)
+    monkeypatch.setenv("RT_SPLIT", "0")
+    _strict_equals_oracle(R, W, H, 2, 2, O.ACCUM_F32, spheres, mats, cam, False)
+
+
 def test_sky_tiles_are_off_for_a_non_finite_camera(monkeypatch):
     """A non-finite pixel_to_world entry - even in the column the shader multiplies by 0.0 - makes every ray NaN, and
     NaN roots pass hit_sphere's range tests (wgsl:214-222): such rays hit. No tile may then be treated as sky."""

@@ -5,11 +5,17 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np
 import raytracer_amd as R
 import oracle_lib as O, scenes
+from raytracer_amd import configs
+
+def bench_scene(name):
+    """the scene bench.py / tools/run_configs.py use for this config (the host mirror's seeded builders)"""
+    c = configs.get(name)
+    return c["spheres"], c["materials"]
 
 def flops(c):
     return O.algorithmic_flops(c)
 
-def run(name, W, H, spp, scene, shade, math, reps=3, accum=R.RT_ACCUM_F32):
+def run(name, W, H, spp, scene, shade, math, reps=int(os.environ.get('QP_REPS', '3')), accum=R.RT_ACCUM_F32):
     sp, mt = scene
     flags = accum | shade | math
     rt = R.Raytracer(W, H, flags)
@@ -46,6 +52,8 @@ if __name__ == "__main__":
         if "c3d" in which:
             run("4K 64spp default", 3840, 2160, 64, scenes.default_scene(1), 0, math)
         if "c3" in which:
-            run("C3 4K 64spp checker20", 3840, 2160, 64, scenes.random_bunch(20, 3, 3), R.RT_SHADE_CHECKER, math)
+            run("C3 4K 64spp checker20", 3840, 2160, 64, bench_scene("C3"), R.RT_SHADE_CHECKER, math)
+        if "c3t" in which:  # the tests' numpy-seeded bunch (another 20 spheres)
+            run("4K 64spp checker20 (tests)", 3840, 2160, 64, scenes.random_bunch(20, 3, 3), R.RT_SHADE_CHECKER, math)
         if "c4" in which:
-            run("C4 1080p 4spp 1024sph", 1920, 1080, 4, scenes.random_bunch(1024, 16, 4), 0, math)
+            run("C4 1080p 4spp 1024sph", 1920, 1080, 4, bench_scene("C4"), 0, math)

@@ -7,6 +7,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import raytracer_amd as R
 import oracle_lib as O, scenes
+from raytracer_amd import configs
+
+def bench_scene(name):
+    c = configs.get(name)
+    return c["spheres"], c["materials"]
 
 def run(name, W, H, spp, scene, shade, math):
     sp, mt = scene
@@ -20,6 +25,12 @@ def run(name, W, H, spp, scene, shade, math):
         rt.set_camera(cam); rt.set_time(int(tb[i])); rt.compute(); rt.sync()
     c = rt.counters()
     life = c["S"]; iters = c["Sm"]
+    only = os.environ.get("SECTION_ONLY")
+    if only is not None:  # library built with -DRT_PROFILE_ONLY=<only>: that section's share with two clock reads per iteration
+        label, key = [("[G] draws", "T"), ("trace prelude", "D"), ("phase 1", "H"), ("phase 2", "R"), ("shade", "M")][int(only)]
+        print(f"ONLY {name} {'fast' if math else 'strict'} | {label} | {100.0 * c[key] / life:.2f} | {c[key] / iters:.0f} | {life / iters:.0f}")
+        rt.close()
+        return
     if os.environ.get("SECTION_LANES") == "hist":  # -DRT_PROFILE_SECTIONS=3: candidates per ray at the walk
         prim = [c[k] for k in ("T", "D", "H", "R", "M")]; bounce = [c[k] for k in ("Sd", "N", "P", "rand_calls")]
         print(f"{name} {'fast' if math else 'strict'}: primary rays with 1, 2, 3, 4, 5+ candidates: " + ", ".join(f"{100.0 * v / max(sum(prim), 1):.1f} %" for v in prim)
@@ -59,7 +70,7 @@ def run(name, W, H, spp, scene, shade, math):
 
 if __name__ == "__main__":
     for math in (R.RT_MATH_STRICT, R.RT_MATH_FAST):
-        run("C3", 3840, 2160, 64, scenes.random_bunch(20, 3, 3), R.RT_SHADE_CHECKER, math)
-        run("C4", 1920, 1080, 4, scenes.random_bunch(1024, 16, 4), 0, math)
+        run("C3", 3840, 2160, 64, bench_scene("C3"), R.RT_SHADE_CHECKER, math)
+        run("C4", 1920, 1080, 4, bench_scene("C4"), 0, math)
         run("C2", 1920, 1080, 16, scenes.default_scene(1), 0, math)
         run("4K default scene", 3840, 2160, 64, scenes.default_scene(1), 0, math)
