@@ -331,6 +331,12 @@ template <bool STRICT, bool COUNT, bool SMALL, bool SPLIT>
 #ifndef RT_SPLIT_WAVES
 #define RT_SPLIT_WAVES 7
 #endif
+#ifndef RT_LIST_BATCH
+#define RT_LIST_BATCH 56u    // LIST shape: READY lanes the general trace waits for ...
+#endif
+#ifndef RT_LIST_MAXSKIP
+#define RT_LIST_MAXSKIP 4u   // ... for at most this many iterations in a row
+#endif
 #ifndef RT_WALK_MIN_LANES
 #define RT_WALK_MIN_LANES 6u   // MASK shape: lanes that must still hold candidates for a further trip of the walk in the same iteration
 #endif
@@ -386,6 +392,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   uint32_t iters = 0;        // trace iterations spent on the current pixel (cost feedback for the tile order)
   uint32_t q_tile = 0, q_tile_new = 0, q_frame = 0;  // wave-uniform: tile (and, staged, frame) being handed out
   uint32_t q_mask = 0, q_mask_new = 0xffffffffu;     // wave-uniform: candidate mask of that tile (SPLIT)
+  uint32_t list_skips = 0;                           // wave-uniform (LIST shape): iterations the general trace has waited for more READY lanes
   uint32_t tmask = 0;                                // candidate spheres of the primary rays of this lane's pixel (SPLIT)
   float pcx = 0, pcy = 0, pcz = 0, pdx = 0, pdy = 0, pdz = 0;  // pixel_center, pixel_delta
   uint32_t k = 0, rng = 0, sample = 0, depth = 0;
@@ -653,6 +660,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   auto trace_general = [&]() __attribute__((always_inline)) {
     if (COUNT && __ballot(state == ST_READY)) c_wt++;
     if (state == ST_READY) {
+      RT_PROF_LANES(1);
       RT_PROF_BEGIN(1);
       iters++;
       float closest = RT_RAY_TMAX;
@@ -1126,6 +1134,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       RT_PROF_BEGIN(0);
       uint32_t lcnt = 0;
       if (state == ST_NEW_RAY) {
+        RT_PROF_LANES(0);
         uint32_t s0, s1;
         RT_STEP(s0); RT_STEP(s1);
         start_ray(s0, s1);
@@ -1143,7 +1152,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         int hit = -1;
         const unsigned long long any_untame = __ballot(!tame);
         const uint16_t* list = a.tile_lists + (size_t)my_tile * 16u + 1u;
-        for (uint32_t j = 0; j < lcnt; ++j) test_sphere(list[j], closest, hit, any_untame);  // ascending sphere index
+        for (uint32_t j = 0; j < lcnt; ++j) { RT_PROF_LANES(3); test_sphere(list[j], closest, hit, any_untame); }  // ascending sphere index
         if (hit < 0) shade_miss(); else shade_hit(closest, hit);
       }
       RT_PROF_END(3);
@@ -1157,7 +1166,16 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       }
       if (state == ST_GOT_DIR) finish_direction();
       RT_PROF_END(0);
-      trace_general();
+      // The general trace costs the wave ~6 instructions per sphere of the scene whoever takes part, the sections above
+      // a few hundred in all: lanes whose primary ray missed (or whose direction is not drawn yet) would sit it out.
+      // So the trace waits - at most RT_LIST_MAXSKIP iterations in a row - until RT_LIST_BATCH lanes are READY,
+      // while the other lanes go round the cheap sections again and join them.
+      {
+        const uint32_t n_ready = (uint32_t)__popcll(__ballot(state == ST_READY));
+        const bool others = __ballot(state == ST_NEW_RAY || state == ST_PATH_DONE || state == ST_NEED_DIR) != 0ull;
+        if (n_ready >= RT_LIST_BATCH || !others || list_skips >= RT_LIST_MAXSKIP) { list_skips = 0; trace_general(); }
+        else if (n_ready) list_skips++;
+      }
     }
   }
 
