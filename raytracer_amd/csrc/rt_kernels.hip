@@ -1331,7 +1331,11 @@ __global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, ui
       const double inner = r2 - L2 * smax * smax;  // r^2 - (distance of the cone's worst line from the centre)^2
       const double ea = 0x1p-6 * r + 0x1p-19 * L;
       if (cpsi > 0.0 && cmax > 0.0 && inner >= 0x1p-12 * (L2 + r2) && (L - r) - ea > RT_RAY_TMIN * (ndc + rho) * (1.0 + 0x1p-10))
+#ifdef RT_BREAK_OCCLUSION  // harness check of tools/fuzz_proofs.py: an unsound bound must show up as mismatches
+        up = (L * cmax - sqrt(inner)) * 0.8;
+#else
         up = (L * cmax - sqrt(inner) + ea) * (1.0 + 0x1p-20);
+#endif
       return false;
     };
     // OCCLUSION. hit_sphere's loop ends with the smallest accepted root and, among equal ones, the lowest index
