@@ -13,7 +13,8 @@ The K timed steps are one render; the render is repeated (each repetition bracke
 least one second has been measured, and `value` is K steps' samples over the MEAN repetition time (`repeats`).
 With N GPUs the default partition is BASELINE config 3's: image tiles (`--split tiles`: rank r renders the 8x8 tiles
 t = r mod N of every frame, "strong" scaling on the fixed 4K frame, bit-identical to the 1-GPU image), the per-GPU
-images combined by ONE RCCL sum-reduce at the end of the render, inside the timed region. `--split frames` (the
+images combined by ONE RCCL collective at the end of the render, inside the timed region (a gather of each rank's own
+tiles onto rank 0; RT_BENCH_COMBINE=reduce uses a sum-reduce of the whole images instead - the same bits). `--split frames` (the
 default for C5, BASELINE config 5) splits the progressive render by disjoint per-frame sample sets instead: in step i
 rank r renders frame i*N + r of the whole image into a float sum, per-GPU work is fixed ("weak" scaling) and a step
 of the job is N frames; the N > 1 line carries the other split's measurement as `other_split`.
@@ -78,6 +79,12 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
     img = rdist.DeviceImage(rt, f"cuda:{device}") if use_dist else None
     if split == "tiles":
         rt.set_partition(rank, world)
+    # tile split: rank 0 needs only each rank's OWN tiles - a gather of 1/N of an image per rank instead of a sum-reduce of
+    # N whole images (same bits; RT_BENCH_COMBINE=reduce keeps the reduce)
+    gather = None
+    if img is not None and split == "tiles" and os.environ.get("RT_BENCH_COMBINE", "gather") == "gather" \
+            and rdist.TileGather.usable(W, H, bool(flags & R.RT_DISPATCH_FULL)):
+        gather = rdist.TileGather(img.tensor, rank, world, dst=0)
     tb = host.time_table(frames_total * (world if split == "frames" else 1))
     cam = host.camera_raw(W, H, spp=spp, frames=frames_total * world)
 
@@ -103,6 +110,16 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
     for i in range(warmup):
         step(i)
     rt.sync()
+    if use_dist:  # the collective's first call sets up RCCL's channels: part of the warm-up, like the kernels' first launches
+        if gather is not None:
+            try:
+                gather.run()
+            except (RuntimeError, ValueError, NotImplementedError) as e:  # a backend without gather: every rank lands here alike
+                print(f"bench.py: tile gather unavailable ({e}); using the sum-reduce", file=sys.stderr)
+                gather = None
+        if gather is None:
+            rdist.combine_sum(img.tensor, dst=0)
+        torch.cuda.synchronize()
     rt.enable_timing(True)
     rt.timing_reset()
     total, repeats, at = 0.0, 0, warmup
@@ -115,7 +132,9 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
         for i in range(at, at + steps):
             step(i)
         rt.sync()
-        if use_dist:
+        if gather is not None:
+            gather.run()                          # ONE RCCL gather per render (tile split)
+        elif use_dist:
             rdist.combine_sum(img.tensor, dst=0)  # ONE RCCL reduce per render
         torch.cuda.synchronize()
         if use_dist:
@@ -138,7 +157,8 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
     cov_w = W if flags & R.RT_DISPATCH_FULL else (W // 16) * 16
     cov_h = H if flags & R.RT_DISPATCH_FULL else (H // 16) * 16
     samples_per_step = cov_w * cov_h * spp * (world if split == "frames" else 1)
-    return {"seconds": seconds, "repeats": repeats, "kernel_ms": kernel_ms, "launches": launches, "counters": counters,
+    return {"combine": "gather" if gather is not None else ("reduce" if use_dist else None),
+            "seconds": seconds, "repeats": repeats, "kernel_ms": kernel_ms, "launches": launches, "counters": counters,
             "flops_per_launch": algorithmic_flops(counters), "samples_per_step": samples_per_step, "device": info,
             # samples finished by the sky-tile bound instead of a trace (full 8x8 tiles: the covered area is a multiple of 16),
             # and the algorithmic FLOPs of their primary rays: N + R + n_spheres x T + M per sample
@@ -332,7 +352,7 @@ def main():
         }
         if use_dist:
             out["config"]["split"] = args.split
-            out["config"]["parallelism"] = (f"{world} GPUs x interleaved 8x8 tiles of every frame, one RCCL reduce per render" if args.split == "tiles"
+            out["config"]["parallelism"] = (f"{world} GPUs x interleaved 8x8 tiles of every frame, one RCCL {m['combine']} per render" if args.split == "tiles"
                                             else f"{world} GPUs x disjoint frame sets of the whole image, one RCCL reduce per render")
         if other_split is not None:
             osplit = "frames" if args.split == "tiles" else "tiles"

@@ -37,6 +37,9 @@ def _worker(rank, world, port, mode, q):
     spheres, mats = scenes.default_scene(1)
     cam = scenes.camera_raw(W, H, spp=spp, frames=frames)
     try:
+        gather = mode.endswith("_gather")
+        if gather:
+            mode = mode[: -len("_gather")]
         if mode in ("tiles_f32", "tiles_rgba8"):
             flags = O.ACCUM_F32 if mode == "tiles_f32" else 0
             img = O.OracleImage(W, H, flags)
@@ -45,7 +48,11 @@ def _worker(rank, world, port, mode, q):
             mine = img.accum if flags else img.rgba8
             assert not mine[~mask].any() and mine[mask][..., 3].all()  # my tiles rendered, others zero
             t = torch.from_numpy(mine.copy())
-            rdist.combine_sum(t, dst=0)
+            if gather:  # the same combine as a gather of each rank's own tiles
+                assert rdist.TileGather.usable(W, H)
+                rdist.TileGather(t, rank, world, dst=0).run()
+            else:
+                rdist.combine_sum(t, dst=0)
             if rank == 0:
                 whole = O.OracleImage(W, H, flags)
                 O.render(whole, spheres, mats, cam, 0, frames, threads=1)
@@ -72,12 +79,13 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["tiles_f32", "tiles_rgba8", "frames"])
-def test_two_rank_combine(mode):
+@pytest.mark.parametrize("mode,world", [("tiles_f32", 2), ("tiles_rgba8", 2), ("frames", 2), ("tiles_f32_gather", 2),
+                                        ("tiles_rgba8_gather", 2), ("tiles_f32_gather", 3)])
+def test_two_rank_combine(mode, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
