@@ -261,14 +261,32 @@ def test_torch_owned_image_and_single_rank_rccl_reduce():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
         started = True
+    ref = O.OracleImage(W, H, flags)
+    O.render(ref, spheres, mats, cam, 0, frames)
     try:
         rdist.combine_sum(img.tensor, dst=0)
         torch.cuda.synchronize()
+        # the tile split's other combine: pack my tiles, (1-rank) RCCL gather, unpack - on the image itself
+        assert rdist.TileGather.usable(W, H)
+        rdist.TileGather(img.tensor, 0, 1, dst=0).run()
+        torch.cuda.synchronize()
+        # ... and its pack / unpack on the device for three ranks: rank r's packed tiles, put back where rank 0 would
+        # put them, rebuild the picture from three images that each hold a third of the tiles
+        whole = img.tensor.clone()
+        rebuilt = torch.zeros_like(whole)
+        for r in range(3):
+            part = whole * torch.from_numpy(rdist.tile_owner_mask(W, H, 3, r)).to(whole.device)[..., None]
+            g = rdist.TileGather(part, r, 3, dst=r)
+            n = g.mine[0].numel()
+            g.send[:n] = g.tiles[g.mine[0], g.mine[1]]
+            dstg = rdist.TileGather(rebuilt, 0, 3, dst=0)
+            ty, tx = dstg.theirs[r]
+            dstg.tiles[ty, tx] = g.send[: ty.numel()]
+        torch.cuda.synchronize()
+        assert torch.equal(rebuilt.view(torch.int32), whole.view(torch.int32))
     finally:
         if started:
             dist.destroy_process_group()
-    ref = O.OracleImage(W, H, flags)
-    O.render(ref, spheres, mats, cam, 0, frames)
     assert np.array_equal(img.tensor.cpu().numpy().view(np.uint32), ref.accum.view(np.uint32))
     assert np.array_equal(rt.read_accum_f32().view(np.uint32), ref.accum.view(np.uint32))
     rt.bind_accum(0, 0)  # back to the context's own image before the tensor dies
