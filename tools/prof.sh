@@ -5,9 +5,10 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-# 8 + 8 passes: the library runs them as two 8-pass launches (RT_DEFER_FRAMES), like the default bench command
-cmd="bench.py --steps 8 --warmup 8 --min-seconds 0 --no-cpu-baseline --no-extras $*"
-export PROF_FRAMES_PER_LAUNCH=${RT_DEFER_FRAMES:-8}
+# 20 + 20 passes: the library runs them as two 20-pass launches (it batches up to RT_DEFER_FRAMES = 24 recorded passes), the
+# launch shape of the driver's bench command (--steps 20); one repetition, no CPU leg, no side measurements
+cmd="bench.py --steps 20 --warmup 20 --min-seconds 0 --no-cpu-baseline --no-extras $*"
+export PROF_FRAMES_PER_LAUNCH=20
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $cmd > $out/trace.log 2>&1 || { tail -5 $out/trace.log; exit 1; }
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS" \
