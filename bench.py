@@ -7,7 +7,7 @@
 A STEP is one compute pass (`rt_compute`, reference Raytracer::compute, src/raytracing.rs:178-200)
 over the whole image of the workload BASELINE.json's metric is quoted on: C3 = 3840x2160, 64 spp,
 glowing-checkers scene (random_bunch(20)). rt_compute, like the reference's compute, records the pass;
-the library runs up to 24 recorded passes as one batched launch when the caller synchronises (bit-identical
+the library runs up to 64 recorded passes (32 at 4K) as one batched launch when the caller synchronises (bit-identical
 to one launch per pass; `per_pass_launches` in the JSON line is the same measurement with RT_DEFER_FRAMES=1).
 The K timed steps are one render; the render is repeated (each repetition bracketed and timed on its own) until at
 least one second has been measured, and `value` is K steps' samples over the MEAN repetition time (`repeats`).

@@ -56,7 +56,8 @@ int rt_set_time(rt_ctx* ctx, uint32_t time_bits);
  * when camera.current_frame >= camera.frames_to_render (raytrace_kernal.wgsl:76).
  * Like the reference's compute, which records the dispatch into a command encoder that App::render submits
  * (app.rs:106-111), rt_compute RECORDS the pass (camera, time). Recorded passes run - as one batched launch of up to
- * 24 passes (RT_DEFER_FRAMES; fewer when a 4 GiB staging buffer of 16 B per pixel and pass holds fewer), bit-identical to
+ * 64 passes (RT_DEFER_FRAMES; at >= 4 samples per pixel no more than a 4 GiB staging buffer of 16 B per pixel and pass
+ * holds: 32 at 4K), bit-identical to
  * one launch per pass - when that many wait or at the next call that observes the image, the
  * counters or the timing (rt_sync, rt_read_*, rt_get_counters, rt_timing_get, ...) or that changes what a recorded
  * pass depends on (scene, camera other than current_frame, partition, stream, bound image, rt_clear, rt_write_image);

@@ -124,7 +124,7 @@ struct rt_ctx {
   // deferred passes: rt_compute records (frame, time bits); the passes run as ONE batched launch when `defer_max` of
   // them wait or when any call observes or changes what they depend on (flush_pending)
   std::vector<uint32_t> pend_frames, pend_time;
-  int defer_max = 24;         // env RT_DEFER_FRAMES (<= 1: every rt_compute launches at once); 8 -> 24: each launch ends on a tail of
+  int defer_max = 64;         // env RT_DEFER_FRAMES (<= 1: every rt_compute launches at once); 8 -> 64: each launch ends on a tail of
                               // one pixel's work per lane (0.4 ms at 4K / 64 spp), 0.7 % of an 8-pass launch on one GPU but 6 % on an eighth of the tiles
   // per-launch timing
   bool timing = false;
@@ -610,11 +610,20 @@ int rt_compute(rt_ctx* ctx) {
   if (ctx->defer_max > 1 && !ctx->counting && ctx->stream == ctx->own_stream) {
     ctx->pend_frames.push_back(ctx->camera.current_frame);
     ctx->pend_time.push_back(ctx->time_bits);
-    // ... but never more than a staged batch has room for (16 B per pixel and pass in the staging buffer): a batch over
-    // that limit would fall back to the pixel-sequential shape and its long tail
+    // ... but, where batches are staged (launch(): >= RT_STAGE_MIN_SPP samples per pixel, few tiles per wave), never more than a staged batch has room
+    // for (16 B per pixel and pass in the staging buffer): a batch over that limit would fall back to the pixel-sequential
+    // shape and its long tail. Batches of fewer samples per pixel are pixel-sequential anyway, and the longer the better
+    // (8K, 1 spp: 33 Gsamples/s in batches of 8, 57 in batches of 64).
     const size_t per_pass = (size_t)ctx->width * ctx->height * sizeof(rt_f32x4);
     const size_t room = RT_STAGE_MAX_BYTES / (per_pass ? per_pass : 1);
-    const size_t limit = room >= 2 && room < (size_t)ctx->defer_max ? room : (size_t)ctx->defer_max;
+    uint32_t cov_w = 0, cov_h = 0;
+    covered(ctx, &cov_w, &cov_h);
+    const uint64_t tiles = (uint64_t)((cov_w + 7u) / 8u) * ((cov_h + 7u) / 8u);
+    const uint64_t my_tiles = tiles > ctx->rank ? (tiles - ctx->rank + ctx->world - 1u) / ctx->world : 0u;
+    // launch()'s staging rule: few tiles per resident wave and enough samples per pixel
+    const bool staged = ctx->use_staging && ctx->camera.samples_per_pixel >= RT_STAGE_MIN_SPP &&
+                        my_tiles < RT_STAGE_BELOW * (uint64_t)ctx->compute_units * 24u;
+    const size_t limit = staged && room >= 2 && room < (size_t)ctx->defer_max ? room : (size_t)ctx->defer_max;
     if (ctx->pend_frames.size() >= limit) RT_FLUSH(ctx);
     return RT_OK;
   }

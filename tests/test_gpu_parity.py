@@ -680,7 +680,7 @@ def test_sky_tiles_follow_the_camera_and_the_scene():
 
 @pytest.mark.parametrize("flags", [0, O.ACCUM_F32, O.ACCUM_F32 | O.COMBINE_SUM], ids=["rgba8", "f32", "f32_sum"])
 def test_deferred_passes_equal_single_launches_and_the_oracle(flags, monkeypatch):
-    """rt_compute records a pass; up to RT_DEFER_FRAMES (default 24) recorded passes run as one batched launch when
+    """rt_compute records a pass; up to RT_DEFER_FRAMES (default 64) recorded passes run as one batched launch when
     the caller synchronises or changes what they depend on. 11 passes (8 + 3), non-consecutive frame indices, a new
     spp after pass 4 and a new scene after pass 7 must give the oracle's image and RNG states, as RT_DEFER_FRAMES=1 does."""
     R = _rt()
@@ -698,7 +698,7 @@ def test_deferred_passes_equal_single_launches_and_the_oracle(flags, monkeypatch
         cam = scenes.camera_raw(W, H, spp=spp, frames=64, current_frame=frame_ix[f])
         O.compute(img, sp, mt, cam, int(tb[f]))
     results = []
-    for defer in ("24", "8", "1"):
+    for defer in ("64", "24", "8", "1"):
         monkeypatch.setenv("RT_DEFER_FRAMES", defer)
         rt = R.Raytracer(W, H, flags)
         rt.enable_rng_capture(True)

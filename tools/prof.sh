@@ -5,7 +5,7 @@ tag=$1; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-# 20 + 20 passes: the library runs them as two 20-pass launches (it batches up to RT_DEFER_FRAMES = 24 recorded passes), the
+# 20 + 20 passes: the library runs them as two 20-pass launches (it batches up to 64 recorded passes, 32 at 4K), the
 # launch shape of the driver's bench command (--steps 20); one repetition, no CPU leg, no side measurements
 cmd="bench.py --steps 20 --warmup 20 --min-seconds 0 --no-cpu-baseline --no-extras $*"
 export PROF_FRAMES_PER_LAUNCH=20
