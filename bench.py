@@ -10,7 +10,7 @@ glowing-checkers scene (random_bunch(20)). rt_compute, like the reference's comp
 the library runs up to 64 recorded passes (32 at 4K) as one batched launch when the caller synchronises (bit-identical
 to one launch per pass; `per_pass_launches` in the JSON line is the same measurement with RT_DEFER_FRAMES=1).
 The K timed steps are one render; the render is repeated (each repetition bracketed and timed on its own) until at
-least one second has been measured, and `value` is K steps' samples over the MEAN repetition time (`repeats`).
+least three seconds have been measured, and `value` is K steps' samples over the MEAN repetition time (`repeats`).
 With N GPUs the default partition is BASELINE config 3's: image tiles (`--split tiles`: rank r renders the 8x8 tiles
 t = r mod N of every frame, "strong" scaling on the fixed 4K frame, bit-identical to the 1-GPU image), the per-GPU
 images combined by ONE RCCL collective at the end of the render, inside the timed region (a gather of each rank's own
@@ -21,9 +21,12 @@ of the job is N frames; the N > 1 line carries the other split's measurement as 
 
 Prints ONE JSON line (rank 0). `value` = covered pixels x spp x K / seconds, whole job, inputs
 resident in HBM, RT_MATH_STRICT (the mode that is bit-identical to the oracle). Extra objects:
-  roofline     FP32 VALU roofline of the trace kernel: algorithmic FLOPs per launch (SURVEY.md §8d
-               formula over device event counters) / average launch duration (hipEvents on the
-               launch stream), against 157.3 TFLOP/s.
+  roofline     FP32 VALU roofline of the trace kernel, against 157.3 TFLOP/s. `frac` = the definition: FLOPs of the
+               REFERENCE ALGORITHM per launch (SURVEY.md §8d formula over the device event counters of a counting
+               launch that traces every tile) / average launch duration (hipEvents on the launch stream).
+               `frac_executed` = the same over the events the production launch really executes (rt_enable_counters
+               mode 2). `valu_busy` / `traffic` are NOT measured by this run: they are read from the committed
+               rocprofv3 --pmc passes of this command (profiles/valu_busy_*.json, traffic_*.json; `*_source` says so).
   cpu_baseline the oracle (scalar C port, OpenMP) timed on this box's host cores on a bounded
                tile sample of the same frame (rank 0, N = 1 only).
   fast_math    the same measurement in RT_MATH_FAST (image within tolerance, not bit-exact).
@@ -40,12 +43,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_VALU_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz (packed FMA)
+FP32_VALU_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41: 256 CU x 256 FLOP/clk x 2.4 GHz
 
 
 def algorithmic_flops(c):
     """17T + 4D + 12H + 6R + 15M + 8S + 12Sm + 11J + 7Sd + 8N + 110P."""
     return (17 * c["T"] + 4 * c["D"] + 12 * c["H"] + 6 * c["R"] + 15 * c["M"] + 8 * c["S"] + 12 * c["Sm"]
+            + 11 * c["J"] + 7 * c["Sd"] + 8 * c["N"] + 110 * c["P"])
+
+
+def executed_flops(c):
+    """FLOPs of the events the production launch executes (rt_enable_counters mode 2), weighted like SURVEY.md §8d: a phase-1
+    filter test is 8 FMAs = 16, an exact hit_sphere test up to its discriminant 17 (the §8d figure), the rest as in §8d."""
+    return (16 * c["T"] + 17 * c["X"] + 4 * c["D"] + 12 * c["H"] + 6 * c["R"] + 15 * c["M"] + 8 * c["S"] + 12 * c["Sm"]
             + 11 * c["J"] + 7 * c["Sd"] + 8 * c["N"] + 110 * c["P"])
 
 
@@ -59,7 +69,7 @@ def parse():
     p.add_argument("--split", default=None, choices=["tiles", "frames"],
                    help="N > 1: tiles = interleaved 8x8 tiles of every frame (strong scaling; default, BASELINE config 3); "
                         "frames = disjoint frame sets of the whole image per GPU (weak scaling; default for C5)")
-    p.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step render until this much time is measured")
+    p.add_argument("--min-seconds", type=float, default=3.0, help="repeat the K-step render until this much time is measured")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the fast_math side measurement")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
@@ -101,7 +111,22 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
     step(0)
     rt.sync()
     counters = rt.counters()
+    # what the production launch EXECUTES (rt_enable_counters mode 2: same loop shape, tile masks / lists, drops and culls as the
+    # timed launches, with counters): phase-1 tests run, exact tests run, rays traced, samples finished in sky tiles
+    executed = None
+    try:
+        rt.enable_counters(2)
+        rt.reset_counters()
+        step(0)
+        rt.sync()
+        executed = dict(rt.counters())
+        occ = rt.occupancy()
+        executed["X"], executed["sky_samples"] = occ["slots_trace"], occ["slots_reject"]
+    except R.RtError as e:  # scenes without a SPLIT shape (33-64 spheres) have no such variant
+        print(f"bench.py: executed-work counters unavailable ({e})", file=sys.stderr)
+        rt.sync()
     rt.enable_counters(False)
+    rt.reset_counters()
     rt.clear()
     if img is not None:
         img.zero_()
@@ -160,14 +185,8 @@ def measure(R, cfg, flags, rank, world, steps, warmup, split, dist, torch, devic
     return {"combine": "gather" if gather is not None else ("reduce" if use_dist else None),
             "seconds": seconds, "repeats": repeats, "kernel_ms": kernel_ms, "launches": launches, "counters": counters,
             "flops_per_launch": algorithmic_flops(counters), "samples_per_step": samples_per_step, "device": info,
-            # samples finished by the sky-tile bound instead of a trace (full 8x8 tiles: the covered area is a multiple of 16),
-            # and the algorithmic FLOPs of their primary rays: N + R + n_spheres x T + M per sample
             "sky_tiles": sky_tiles, "my_tiles": my_tiles,
-            "sky_flops_per_launch": sky_tiles * 64 * spp * (8 + 6 + 17 * int(cfg["spheres"].shape[0]) + 15),
-            # phase-1 tests (17 FLOPs each) the primary rays of the traced tiles do not run: they are traced
-            # against their tile's candidate mask / list (<= 32 or > 64 spheres, non-counting launches)
-            "primary_p1_flops_per_launch": (my_tiles - sky_tiles) * 64 * spp * 17 * int(cfg["spheres"].shape[0])
-            if (int(cfg["spheres"].shape[0]) <= 32 or int(cfg["spheres"].shape[0]) > 64) and os.environ.get("RT_SPLIT", "1") != "0" else 0}
+            "executed": executed, "executed_flops_per_launch": executed_flops(executed) if executed else None}
 
 
 def cpu_baseline(cfg, flags, target_seconds):
@@ -282,25 +301,20 @@ def main():
         del os.environ["RT_DEFER_FRAMES"]
 
     if rank == 0:
-        def traffic(math, passes_per_launch, staged):
-            # HBM bytes per launch from the committed PMC pass of this same command (profiles/traffic_*.json holds the
-            # TCC_EA0 byte count of a staged 8-pass launch, PER PASS: a staged launch writes 16 B per pixel and pass,
-            # so its traffic is linear in the passes of the launch), or null where no PMC pass covers the launch shape
-            path = os.path.join(ROOT, "profiles", f"traffic_{args.config}_{math}.json")
+        def committed(kind, math):
+            """A figure that this run does NOT measure: read from the committed PMC pass of this same command under profiles/."""
+            path = os.path.join("profiles", f"{kind}_{args.config}_{math}.json")
             try:
-                t = json.load(open(path))
-                if world != 1 or not staged:
-                    return None
-                return t["bytes_per_pass"] * passes_per_launch
-            except (OSError, ValueError, KeyError):
-                return None
+                return json.load(open(os.path.join(ROOT, path))), path
+            except (OSError, ValueError):
+                return None, None
 
-        def roof(mm, math=None):
+        def roof(mm, math=None, brief=False):
+            math = math or args.math
             launches = max(mm["launches"], 1)
             fpl = args.steps * mm["repeats"] / launches  # passes (frames) per kernel launch
             avg_ms = mm["kernel_ms"] / launches
             achieved = mm["flops_per_launch"] * fpl / (avg_ms * 1e-3) / 1e12
-            traced = (mm["flops_per_launch"] - mm["sky_flops_per_launch"] - mm["primary_p1_flops_per_launch"]) * fpl / (avg_ms * 1e-3) / 1e12
             px = cfg["width"] // 16 * 16 * (cfg["height"] // 16 * 16)
             f32 = bool(base_flags & R.RT_ACCUM_F32)
             # path kernel: the image read + written once per launch, or - in a staged batch (the library's rule: several
@@ -308,23 +322,41 @@ def main():
             tiles = px // 64
             staged = fpl > 1 and cfg["spp"] >= 4 and tiles < 32 * 24 * mm["device"]["compute_units"]
             alg_traffic = px * (16 * fpl if staged else (32 if f32 else 8))
-            return {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
-                    # the same with the work the kernel PROVES unnecessary taken out of the numerator - the samples of sky tiles and the
-                    # phase-1 tests of primary rays (traced against their tile's candidates instead): what the hit loop itself executes
-                    "achieved_traced_only": round(traced, 3), "frac_traced_only": round(traced / FP32_VALU_PEAK_TFLOPS, 4),
-                    "sky_tiles": mm["sky_tiles"], "tiles": mm["my_tiles"],
-                    "traffic": traffic(math or args.math, fpl, staged),
-                    "traffic_algorithmic": int(alg_traffic),
-                    "kernel": "rt_path_kernel", "avg_launch_ms": round(avg_ms, 4), "launches": launches, "passes_per_launch": fpl,
-                    "algorithmic_flops_per_launch": int(mm["flops_per_launch"] * fpl),
-                    "note": "FP32 vector roofline (no MFMA: no dense contraction); peak is the packed-FMA figure, "
-                            "78.6 TFLOP/s for non-packed FMA; FLOPs = SURVEY §8d formula over device event counters "
-                            "of one launch" + (" of rank 0's tiles" if world > 1 else "") +
-                            "; tiles whose primary rays provably miss every sphere are finished without tracing, and the primary rays of "
-                            "the other tiles are tested only against the spheres their tile can see (both bit-identical to the full "
-                            "loop): the algorithmic FLOPs of that avoided work count in `achieved` (the definition: the reference "
-                            "algorithm's FLOPs / time) and are excluded from `achieved_traced_only`"}
+            frac = achieved / FP32_VALU_PEAK_TFLOPS
+            note = ("FP32 vector roofline (no MFMA: no dense contraction, and FP32 MFMA shares the vector pipe, profiles/r3_mfma_coexec.txt); "
+                    "peak 157.3 TFLOP/s = 64 FLOP per clock and SIMD, reached by v_pk_fma_f32 or by two dual-issued v_fma_f32 alike "
+                    "(profiles/r3_valu_ceiling.txt). `frac` is the DEFINITION (SURVEY 8d): FLOPs of the REFERENCE ALGORITHM (every ray "
+                    "tests every sphere; device event counters of a counting launch" + (" of rank 0's tiles" if world > 1 else "") +
+                    ") / the timed kernel's duration. The timed kernel proves part of that work unnecessary and does not run it (sky "
+                    "tiles, primary rays tested against their tile's candidates only, own-sphere drop, behind cull - all bit-identical): "
+                    "`frac_executed` counts the events it does execute (rt_enable_counters mode 2; a phase-1 filter test = 16 FLOPs, "
+                    "an exact test = 17, the rest as 8d) and is the utilisation figure")
+            if frac > 1.0:
+                note = "numerator includes work proven unnecessary (frac > 1: the timed kernel does not execute the counted work). " + note
+            out = {"bound": "valu", "achieved": round(achieved, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(frac, 4)}
+            if mm["executed_flops_per_launch"] is not None:
+                ex = mm["executed_flops_per_launch"] * fpl / (avg_ms * 1e-3) / 1e12
+                e = mm["executed"]
+                out.update({"achieved_executed": round(ex, 3), "frac_executed": round(ex / FP32_VALU_PEAK_TFLOPS, 4),
+                            "executed_per_pass": {"phase1_tests": e["T"], "exact_tests": e["X"], "rays": e["R"], "samples": e["N"],
+                                                  "sky_tile_samples": e["sky_samples"], "rejection_tries": e["J"],
+                                                  "reference_algorithm_tests": mm["counters"]["T"], "reference_algorithm_rays": mm["counters"]["R"]}})
+            vb, vb_path = committed("valu_busy", math)
+            if vb is not None and world == 1:
+                out.update({"valu_busy": vb["valu_busy"], "valu_dual_issue_share": vb["valu2_share"], "lane_utilisation": vb["lane_utilisation"],
+                            "valu_busy_source": f"{vb_path}: rocprofv3 --pmc pass of this command, NOT measured in this run; "
+                                                "4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (SIMDs x cycles), calibrated in profiles/r3_valu_ceiling.txt"})
+            tr, tr_path = committed("traffic", math)
+            traffic = tr["bytes_per_pass"] * fpl if (tr is not None and world == 1 and staged and "bytes_per_pass" in tr) else None
+            out.update({"sky_tiles": mm["sky_tiles"], "tiles": mm["my_tiles"],
+                        "traffic": traffic,
+                        "traffic_source": (f"{tr_path}: TCC_EA0 request counters of a separate rocprofv3 --pmc pass of this command, bytes per pass x "
+                                           "passes per launch; NOT measured in this run") if traffic is not None else None,
+                        "traffic_algorithmic": int(alg_traffic),
+                        "kernel": "rt_path_kernel", "avg_launch_ms": round(avg_ms, 4), "launches": launches, "passes_per_launch": fpl,
+                        "algorithmic_flops_per_launch": int(mm["flops_per_launch"] * fpl),
+                        "note": ("numerator includes work proven unnecessary; " if frac > 1.0 else "") + "see roofline.note" if brief else note})
+            return out
 
         total_samples = m["samples_per_step"] * args.steps
         out = {
@@ -362,12 +394,14 @@ def main():
         other = "fast" if args.math == "strict" else "strict"
         if extras is not None:
             out[f"{other}_math"] = {"value": extras["samples_per_step"] * args.steps / extras["seconds"], "unit": "samples/s",
-                                    "ms_per_step": extras["seconds"] * 1e3 / args.steps, "roofline": roof(extras, other),
-                                    "parity": "image within PSNR >= 40 dB of strict; RNG function bit-exact" if other == "fast"
-                                    else "bit-identical to the oracle"}
+                                    "ms_per_step": extras["seconds"] * 1e3 / args.steps, "roofline": roof(extras, other, brief=True),
+                                    "parity": ("tolerance (PSNR >= 40 dB, max-abs <= 3/255 on unchanged trajectories, >= 99 % identical RNG states) "
+                                               "holds on C1, C2, C3 and C5; NOT met on C4 (39.3 dB, 91.5 % identical states: "
+                                               "tests/test_gpu_golden.py pins what it measures there); RNG function bit-exact everywhere")
+                                    if other == "fast" else "bit-identical to the oracle"}
         if per_pass is not None:
             out["per_pass_launches"] = {"value": per_pass["samples_per_step"] * args.steps / per_pass["seconds"], "unit": "samples/s",
-                                        "ms_per_step": per_pass["seconds"] * 1e3 / args.steps, "roofline": roof(per_pass),
+                                        "ms_per_step": per_pass["seconds"] * 1e3 / args.steps, "roofline": roof(per_pass, brief=True),
                                         "note": "RT_DEFER_FRAMES=1: every rt_compute is its own kernel launch (each with its own tail)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, base_flags, args.cpu_seconds)

@@ -56,8 +56,9 @@ int rt_set_time(rt_ctx* ctx, uint32_t time_bits);
  * when camera.current_frame >= camera.frames_to_render (raytrace_kernal.wgsl:76).
  * Like the reference's compute, which records the dispatch into a command encoder that App::render submits
  * (app.rs:106-111), rt_compute RECORDS the pass (camera, time). Recorded passes run - as one batched launch of up to
- * 64 passes (RT_DEFER_FRAMES; at >= 4 samples per pixel no more than a 4 GiB staging buffer of 16 B per pixel and pass
- * holds: 32 at 4K), bit-identical to
+ * 64 passes (RT_DEFER_FRAMES; at >= 4 samples per pixel no more than the staging buffer holds - 16 B per pixel OF THIS
+ * CONTEXT'S PARTITION and pass, allocated on first use, at most 4 GiB and never more than a quarter of the device memory that
+ * is free when the context first asks: 32 passes of a whole 4K image, 64 of an eighth of it), bit-identical to
  * one launch per pass - when that many wait or at the next call that observes the image, the
  * counters or the timing (rt_sync, rt_read_*, rt_get_counters, rt_timing_get, ...) or that changes what a recorded
  * pass depends on (scene, camera other than current_frame, partition, stream, bound image, rt_clear, rt_write_image);
@@ -82,8 +83,13 @@ int rt_render_frames(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_frames);
  * 2.1 MB array in the library's device image, one copy per GPU, held until the process ends. Limits, rejected with
  * RT_ERR_INVALID and a message: n_frames <= 256; at most 524 288 8x8 tiles in the context's partition (an 8K image has
  * 518 400). RT_ERR_STATE while passes recorded by rt_compute are pending (call rt_sync first). Every call on a GPU
- * shares that GPU's array and rewrites what it uses, so two calls that overlap on one GPU (two contexts on different
- * streams) race; calls on one stream, or separated by rt_sync, do not. Not used here: staged (tile, frame) batches,
+ * shares that GPU's array and rewrites what it uses. Calls from different streams (two contexts of one GPU, each on its own
+ * stream) are ordered on the device by the library: each call records one per-GPU event behind its kernels and a call from
+ * another stream waits for it (hipStreamWaitEvent; no host wait) - they run one after the other, never overlapped. The
+ * exception is a stream under capture, which cannot wait for an event recorded outside its graph: a captured call is not
+ * ordered against other users of that GPU's scratch, and neither is a replay of its graph - the caller keeps them apart.
+ * The frame table is built on the device from the time bits, which travel as kernel arguments: a captured call (any
+ * n_frames <= 256) replays with the seeds and weights it was captured with. Not used here: staged (tile, frame) batches,
  * the cost-ordered tile queue, the per-tile candidate lists of scenes with more than 64 spheres and per-launch timing
  * events, all of which need buffers of their own - expect a few per cent less throughput than rt_render_frames on
  * small scenes and the round-1 loop shape (about 25 % less) on scenes of more than 64 spheres. Asynchronous like
@@ -120,7 +126,14 @@ int rt_read_rng_state(rt_ctx* ctx, void* dst, size_t bytes);
 
 /* Event counters (rays, sphere tests, ... rt_counters in rt_types.h) accumulated by passes run
  * while counting is enabled; they feed rays/s and the algorithmic-FLOP roofline figure. Counting
- * launches an instrumented kernel variant, so leave it off in timed runs. */
+ * launches an instrumented kernel variant, so leave it off in timed runs.
+ *   enable = 1: the events of the REFERENCE ALGORITHM (every tile traced, every sphere tested by every ray: the oracle's
+ *               counters; SURVEY 8d's FLOP formula is defined over these);
+ *   enable = 2: the events the production launch EXECUTES - the same loop shape, tile masks / lists, own-sphere drop and
+ *               behind cull as a non-counting launch. T = phase-1 filter tests run (8 FMAs each), slots_trace = exact
+ *               hit_sphere tests run, D = of those with a discriminant >= 0, R = rays traced (sky-tile samples have none),
+ *               slots_reject = samples finished in sky tiles (their N, M, P and rand_calls are included). RT_ERR_STATE at
+ *               the launch when the scene has no SPLIT shape (33-64 spheres, RT_SPLIT=0 or RT_SKY_TILES=0). */
 int rt_enable_counters(rt_ctx* ctx, int enable);
 int rt_get_counters(rt_ctx* ctx, rt_counters* out); /* synchronous */
 int rt_reset_counters(rt_ctx* ctx);

@@ -52,6 +52,12 @@ namespace {
 constexpr int RT_MAX_DEVICES = 64;
 std::mutex g_scratch_mutex;
 unsigned char* g_scratch_ptr[RT_MAX_DEVICES] = {};
+// Every context of a GPU shares that GPU's scratch, and by default every context has a stream of its own: the users of the
+// scratch are ordered ON THE DEVICE by one event per GPU - recorded behind each static launch, waited for (hipStreamWaitEvent,
+// no host wait, no allocation) by the next static launch that comes from a different stream.
+hipEvent_t g_scratch_event[RT_MAX_DEVICES] = {};
+hipStream_t g_scratch_last_stream[RT_MAX_DEVICES] = {};
+bool g_scratch_used[RT_MAX_DEVICES] = {};
 
 // Device address of this device's copy of the scratch array; resolved once per device, with that device current
 // (rt_create calls this right after hipSetDevice).
@@ -62,6 +68,7 @@ int resolve_scratch(int device) {
   void* p = nullptr;
   RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(rt_static_scratch)));
   if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress(rt_static_scratch) returned null");
+  RT_HIP(hipEventCreateWithFlags(&g_scratch_event[device], hipEventDisableTiming));
   g_scratch_ptr[device] = static_cast<unsigned char*>(p);
   return RT_OK;
 }
@@ -99,7 +106,7 @@ struct rt_ctx {
   int waves_per_cu = 0;       // launch width override (0 = default); env RT_WAVES_PER_CU
   int reject_tries = 0;       // rejection rounds override (0 = default); env RT_REJECT_TRIES
   int batch_lanes = 0;        // parked-lane batch override (0 = default); env RT_BATCH_LANES
-  bool counting = false;
+  int counting = 0;           // 0 off, 1 the reference algorithm's events (classic shape, every tile traced), 2 the events the production shape executes
   float* sph_p1 = nullptr;
   rt_f32x4 *sph_test = nullptr, *sph_shade = nullptr, *sph_col = nullptr;
   bool p1_tame = false;  // every sphere within the magnitude range of the phase-1 error bound
@@ -114,12 +121,12 @@ struct rt_ctx {
   size_t time_cap = 0;
   hipEvent_t time_copied = nullptr;
   bool time_pending = false;
-  uint2* static_time_host = nullptr;  // pinned, RT_STATIC_MAX_FRAMES entries, allocated by rt_create for rt_render_frames_static
   // RGBA8 view of a float image
   void* quant = nullptr;
   // staged launches: frame colours of a batch (n_frames x width x height float4)
   rt_f32x4* staging = nullptr;
   size_t staging_bytes = 0;
+  size_t stage_cap = 0;       // largest staging buffer this context allocates (stage_limit(); 0 = not asked yet)
   int use_staging = 1;        // env RT_STAGED_FRAMES=0 keeps batched launches pixel-sequential
   // deferred passes: rt_compute records (frame, time bits); the passes run as ONE batched launch when `defer_max` of
   // them wait or when any call observes or changes what they depend on (flush_pending)
@@ -155,6 +162,21 @@ constexpr uint32_t RT_ORDER_REFRESH = 32;  // launches between two measurements 
 constexpr uint64_t RT_STAGE_BELOW = 32;    // batches are staged per frame when a rank has fewer tiles per wave than this
 constexpr uint32_t RT_STAGE_MIN_SPP = 4;   // below that a (tile, frame) unit is too little work for its hand-out (C1: 1 spp got slower)
 constexpr size_t RT_STAGE_MAX_BYTES = (size_t)4 << 30;  // largest staging buffer a context allocates
+
+// Largest staging buffer a context may allocate: RT_STAGE_MAX_BYTES, and never more than a quarter of the device memory
+// that is free right now (a plain rt_compute loop must not take gigabytes inside an observer call unasked).
+size_t stage_limit(rt_ctx* ctx) {
+  if (ctx->stage_cap == 0) {  // asked once per context
+    size_t free_b = 0, total_b = 0;
+    ctx->stage_cap = RT_STAGE_MAX_BYTES;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      if (free_b / 4u < ctx->stage_cap) ctx->stage_cap = free_b / 4u;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  return ctx->stage_cap;
+}
 
 float frame_cw(uint32_t frame) {
   // combine_pixel_cache_color (wgsl:107-109): cw = f32(frame) / f32(frame + 1), one IEEE division
@@ -217,9 +239,9 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // RT_STAGE_BELOW tiles per wave (and at least RT_STAGE_MIN_SPP samples per pixel), the unit of work becomes (tile, frame): the frames' colours go to a
   // staging buffer and a second kernel folds them into the image in order (same arithmetic, bit-identical).
   a.n_units = my_tiles;
-  const size_t stage_bytes = (size_t)n_frames * ctx->width * ctx->height * sizeof(rt_f32x4);
+  const size_t stage_bytes = (size_t)n_frames * my_tiles * 64u * sizeof(rt_f32x4);  // the rank's own tiles only
   if (!scratch && ctx->use_staging && n_frames > 1 && time_table_dev && a.spp >= RT_STAGE_MIN_SPP && (uint64_t)my_tiles < RT_STAGE_BELOW * resident &&
-      stage_bytes <= RT_STAGE_MAX_BYTES && (uint64_t)my_tiles * n_frames < 0xffffffffull / 64u) {
+      stage_bytes <= stage_limit(ctx) && (uint64_t)my_tiles * n_frames < 0xffffffffull / 64u) {
     if (ctx->staging_bytes < stage_bytes) {
       RT_HIP(hipStreamSynchronize(ctx->stream));
       (void)hipFree(ctx->staging);
@@ -242,7 +264,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // when there are enough units of work to keep 28 waves per CU busy to the end (C3 -1.5 %, batched C2 -4 %; one C2
   // pass with 4.5 tiles per wave: +4 %, so not there)
   uint32_t wpc = 24u;
-  if (!ctx->counting && a.n_spheres <= 64u /* RT_SMALL_MAX */ && (uint64_t)a.n_units >= 8ull * 28ull * (uint64_t)ctx->compute_units) wpc = 28u;
+  if (ctx->counting == 0 && a.n_spheres <= 64u /* RT_SMALL_MAX */ && (uint64_t)a.n_units >= 8ull * 28ull * (uint64_t)ctx->compute_units) wpc = 28u;
   if (ctx->waves_per_cu > 0) wpc = (uint32_t)ctx->waves_per_cu;
   const uint64_t launch_waves = (uint64_t)ctx->compute_units * wpc;
   const uint32_t n_waves = (uint32_t)(launch_waves < a.n_units ? launch_waves : a.n_units);
@@ -292,13 +314,13 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // (15 us at 4K, once per scene/camera) and rt_combine_frames_kernel (0.25 ms per 8-pass 4K batch, 0.3 % of the path
   // kernel) are lines of their own in the rocprofv3 summaries under profiles/.
   // Counting launches trace every tile, so their event counters stay the oracle's.
-  if (scratch && ctx->use_sky && !ctx->counting) {
+  if (scratch && ctx->use_sky && ctx->counting != 1) {
     // the scratch is shared by every context on this GPU and keeps the last call's contents: the flags of this
     // context's my_tiles tiles are rewritten by every call (15 us at 4K)
     uint32_t* flags = reinterpret_cast<uint32_t*>(scratch + RT_STATIC_OFF_SKY);
     RT_HIP(rt_launch_tile_masks(a, flags, nullptr, ctx->stream));  // no room for candidate lists in the static scratch
     a.tile_masks = flags;
-  } else if (ctx->use_sky && !ctx->counting) {
+  } else if (ctx->use_sky && ctx->counting != 1) {
     if (ctx->sky_tiles_cap != my_tiles) {
       RT_HIP(hipStreamSynchronize(ctx->stream));
       (void)hipFree(ctx->sky_flags);
@@ -323,8 +345,11 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   RT_HIP(hipMemsetAsync(a.queue, 0, sizeof(uint32_t), ctx->stream));
   if (timing) RT_HIP(hipEventRecord(e0, ctx->stream));
   // SPLIT variant (primary rays traced against their tile's candidate mask, primary + first bounce per iteration)
-  const bool split = ctx->use_split && a.tile_masks && !ctx->counting && (a.n_spheres <= 32u || a.tile_lists);
-  RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting, split, ctx->stream));
+  const bool split = ctx->use_split && a.tile_masks && ctx->counting != 1 && (a.n_spheres <= 32u || a.tile_lists);
+  if (ctx->counting == 2 && !split)
+    return fail(RT_ERR_STATE, "rt_enable_counters(2): the executed-work counters exist for the SPLIT launch shapes only (<= 32 or > 64 spheres, "
+                              "tile masks and RT_SPLIT on)");
+  RT_HIP(rt_launch_path_kernel(a, n_waves, strict, ctx->counting != 0, split, ctx->stream));
   if (timing) {
     RT_HIP(hipEventRecord(e1, ctx->stream));
     ctx->events_used++;
@@ -371,26 +396,15 @@ int launch_batch(rt_ctx* ctx, const uint32_t* frames, const uint32_t* time_bits,
   return launch(ctx, frames[0], n, time_bits[0], ctx->time_dev);
 }
 
-// launch_batch for rt_render_frames_static: the frame table goes through the context's pinned buffer (allocated by
-// rt_create) into the static scratch; no allocation on any path.
-int launch_batch_static(rt_ctx* ctx, const uint32_t* frames, const uint32_t* time_bits, uint32_t n, unsigned char* scratch) {
+// launch_batch for rt_render_frames_static: the frame table is written into the static scratch by a one-workgroup kernel that
+// takes the time bits BY VALUE (1 KiB of kernel arguments) - no pinned buffer, no event, no host wait: the call is the same
+// sequence of stream operations whether it runs or is being captured, and a replayed graph carries its own table.
+int launch_batch_static(rt_ctx* ctx, uint32_t first_frame, const uint32_t* time_bits, uint32_t n, unsigned char* scratch) {
   if (n == 0) return RT_OK;
-  if (n == 1) return launch(ctx, frames[0], 1, time_bits[0], nullptr, scratch);
-  if (ctx->time_pending) {  // a pinned table may still be in flight from the previous batch
-    RT_HIP(hipEventSynchronize(ctx->time_copied));
-    ctx->time_pending = false;
-  }
-  for (uint32_t i = 0; i < n; ++i) {
-    const float cw = frame_cw(frames[i]);
-    uint32_t cw_bits;
-    std::memcpy(&cw_bits, &cw, 4);
-    ctx->static_time_host[i] = make_uint2(time_bits[i] * 87189u + 189273u, cw_bits);
-  }
+  if (n == 1) return launch(ctx, first_frame, 1, time_bits[0], nullptr, scratch);
   uint2* table = reinterpret_cast<uint2*>(scratch + RT_STATIC_OFF_TABLE);
-  RT_HIP(hipMemcpyAsync(table, ctx->static_time_host, n * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-  RT_HIP(hipEventRecord(ctx->time_copied, ctx->stream));
-  ctx->time_pending = true;
-  return launch(ctx, frames[0], n, time_bits[0], table, scratch);
+  RT_HIP(rt_launch_frame_table(table, time_bits, first_frame, n, ctx->stream));
+  return launch(ctx, first_frame, n, time_bits[0], table, scratch);
 }
 
 // Launches the passes rt_compute has recorded. Called by every entry point that observes the image, the counters or
@@ -456,7 +470,6 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e7 = std::getenv("RT_DEFER_FRAMES")) c->defer_max = std::atoi(e7);
   if (const char* e8 = std::getenv("RT_SPLIT")) c->use_split = std::atoi(e8);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&c->static_time_host, RT_STATIC_MAX_FRAMES * sizeof(uint2), hipHostMallocDefault);
   if (e == hipSuccess) {
     c->stream = c->own_stream;
     e = hipMemsetAsync(c->accum, 0, c->accum_bytes, c->stream);
@@ -500,7 +513,6 @@ void rt_destroy(rt_ctx* c) {
   (void)hipFree(c->quant);
   (void)hipFree(c->staging);
   if (c->time_host) (void)hipHostFree(c->time_host);
-  if (c->static_time_host) (void)hipHostFree(c->static_time_host);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -607,19 +619,19 @@ int rt_compute(rt_ctx* ctx) {
   // pays) - bit-identical to launching them one by one, without each launch's tail. Counting launches stay single.
   // On a caller's stream (rt_set_stream) every pass is enqueued at once: such callers order their own work after ours
   // on that stream (RCCL on the same stream, graph capture) and must find the kernel there.
-  if (ctx->defer_max > 1 && !ctx->counting && ctx->stream == ctx->own_stream) {
+  if (ctx->defer_max > 1 && ctx->counting == 0 && ctx->stream == ctx->own_stream) {
     ctx->pend_frames.push_back(ctx->camera.current_frame);
     ctx->pend_time.push_back(ctx->time_bits);
     // ... but, where batches are staged (launch(): >= RT_STAGE_MIN_SPP samples per pixel, few tiles per wave), never more than a staged batch has room
     // for (16 B per pixel and pass in the staging buffer): a batch over that limit would fall back to the pixel-sequential
     // shape and its long tail. Batches of fewer samples per pixel are pixel-sequential anyway, and the longer the better
     // (8K, 1 spp: 33 Gsamples/s in batches of 8, 57 in batches of 64).
-    const size_t per_pass = (size_t)ctx->width * ctx->height * sizeof(rt_f32x4);
-    const size_t room = RT_STAGE_MAX_BYTES / (per_pass ? per_pass : 1);
     uint32_t cov_w = 0, cov_h = 0;
     covered(ctx, &cov_w, &cov_h);
     const uint64_t tiles = (uint64_t)((cov_w + 7u) / 8u) * ((cov_h + 7u) / 8u);
     const uint64_t my_tiles = tiles > ctx->rank ? (tiles - ctx->rank + ctx->world - 1u) / ctx->world : 0u;
+    const size_t per_pass = (size_t)my_tiles * 64u * sizeof(rt_f32x4);  // the staging buffer holds this rank's own tiles
+    const size_t room = stage_limit(ctx) / (per_pass ? per_pass : 1);
     // launch()'s staging rule: few tiles per resident wave and enough samples per pixel
     const bool staged = ctx->use_staging && ctx->camera.samples_per_pixel >= RT_STAGE_MIN_SPP &&
                         my_tiles < RT_STAGE_BELOW * (uint64_t)ctx->compute_units * 24u;
@@ -665,9 +677,21 @@ int rt_render_frames_static(rt_ctx* ctx, const uint32_t* time_bits, uint32_t n_f
   const uint32_t cur = ctx->camera.current_frame, total = ctx->camera.frames_to_render;
   const uint32_t live = cur < total ? (n_frames < total - cur ? n_frames : total - cur) : 0u;  // rest are no-ops (wgsl:76)
   if (live > 0) {
-    uint32_t frames[RT_STATIC_MAX_FRAMES];
-    for (uint32_t i = 0; i < live; ++i) frames[i] = cur + i;
-    if (int rc = launch_batch_static(ctx, frames, time_bits, live, scratch)) return rc;
+    // Order this call behind the scratch's last user when that was another stream (another context of this GPU). A stream
+    // that is being captured cannot wait for an event recorded outside the capture: there the caller orders the graph
+    // against other users of this GPU's scratch (rt_hip.h).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    RT_HIP(hipStreamIsCapturing(ctx->stream, &cap));
+    const bool ordered = cap == hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);  // held over the enqueue: two host threads must not interleave their scratch users either
+    if (ordered && g_scratch_used[ctx->device] && g_scratch_last_stream[ctx->device] != ctx->stream)
+      RT_HIP(hipStreamWaitEvent(ctx->stream, g_scratch_event[ctx->device], 0));
+    if (int rc = launch_batch_static(ctx, cur, time_bits, live, scratch)) return rc;
+    if (ordered) {
+      RT_HIP(hipEventRecord(g_scratch_event[ctx->device], ctx->stream));
+      g_scratch_last_stream[ctx->device] = ctx->stream;
+      g_scratch_used[ctx->device] = true;
+    }
   }
   ctx->camera.current_frame = cur + n_frames;
   ctx->time_bits = time_bits[n_frames - 1];
@@ -748,7 +772,8 @@ int rt_read_rng_state(rt_ctx* ctx, void* dst, size_t bytes) {
 int rt_enable_counters(rt_ctx* ctx, int enable) {
   if (int rc = check(ctx)) return rc;
   RT_FLUSH(ctx);
-  ctx->counting = enable != 0;
+  if (enable < 0 || enable > 2) return fail(RT_ERR_INVALID, "rt_enable_counters: 0 = off, 1 = the reference algorithm's events, 2 = the events the production launch executes");
+  ctx->counting = enable;
   return RT_OK;
 }
 

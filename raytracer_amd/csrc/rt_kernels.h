@@ -39,7 +39,7 @@ struct rt_kargs {
   const rt_f32x4* sph_shade;
   const rt_f32x4* sph_col;
   void* accum;                   // RGBA8: uint32 per pixel; F32: float4 per pixel
-  rt_f32x4* staging;             // staged launch: n_frames x width x height frame colours, else null
+  rt_f32x4* staging;             // staged launch: n_frames x my_tiles x 64 frame colours (this rank's own tiles, pixel (v & 7) * 8 + (u & 7) within the tile), else null
   uint32_t* rng_out;             // optional
   unsigned long long* counters;  // 14 x u64, COUNT variants only
   uint32_t* queue;               // tile queue head, zeroed on the stream before every launch
@@ -62,4 +62,7 @@ hipError_t rt_launch_combine_frames(const rt_kargs& a, hipStream_t stream);
 // lists (optional, scenes of > 32 spheres): the same as a short list per tile (rt_kargs::tile_lists)
 hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, uint16_t* lists, hipStream_t stream);
 hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t n, hipStream_t stream);
+// table[i] = {time_bits_host[i] * 87189 + 189273, bits of f32(first_frame + i) / f32(first_frame + i + 1)}, i < n <= 256; the time
+// bits travel as kernel arguments (copied at the call)
+hipError_t rt_launch_frame_table(uint2* table, const uint32_t* time_bits_host, uint32_t first_frame, uint32_t n, hipStream_t stream);
 hipError_t rt_launch_quantize(const void* src_f32x4, void* dst_rgba8, size_t n_pixels, hipStream_t stream);

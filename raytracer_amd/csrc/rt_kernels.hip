@@ -341,12 +341,14 @@ template <bool STRICT, bool COUNT, bool SMALL, bool SPLIT>
 #define RT_WALK_MIN_LANES 6u   // MASK shape: lanes that must still hold candidates for a further trip of the walk in the same iteration
 #endif
 __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7) : RT_MIN_WAVES) void rt_path_kernel(const rt_kargs a) {
-  static_assert(!SPLIT || !COUNT, "SPLIT needs the tile masks / lists, which counting launches do not use");
+  // COUNT && SPLIT = the production shape with counters: what the kernel EXECUTES (rt_enable_counters mode 2), as opposed to
+  // COUNT && !SPLIT, which traces every tile in the classic shape so that its counters are the reference algorithm's (the oracle's).
+  constexpr bool EXEC = COUNT && SPLIT;
   constexpr bool MASK = SPLIT && SMALL;   // <= 32 spheres: the tile's candidates are a bit mask, every section once per iteration
   constexpr bool LIST = SPLIT && !SMALL;  // > 64 spheres: the tile's candidates are a short list; primary and general trace
   // behind cull: strict small-scene launches (fewer exact tests), and every SPLIT launch (there a bounce ray without
   // candidates is finished on the spot, so candidates that only fall to the exact test cost a loop iteration)
-  constexpr bool QUEUE = STRICT && !SMALL && !COUNT;  // the general trace collects a ray's candidates over all blocks before the exact tests
+  constexpr bool QUEUE = STRICT && !SMALL && (!COUNT || SPLIT);  // the general trace collects a ray's candidates over all blocks before the exact tests
   constexpr bool CULL = SMALL && (STRICT || SPLIT);  // (the 1024-sphere scene loses 2 % with it: one more instruction per sphere)
   // The lane index is recomputed where the cold code needs it (two v_mbcnt behind a compiler barrier) instead of
   // living in a register across the hot loop: at 72 registers that one value was the last spill.
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
 
   uint32_t c_T = 0, c_D = 0, c_H = 0, c_R = 0, c_M = 0, c_S = 0, c_Sm = 0, c_J = 0, c_Sd = 0, c_N = 0, c_P = 0, c_rand = 0;
   uint32_t c_wt = 0, c_wr = 0;  // wave-level iteration counts (diagnostics)
+  uint32_t c_X = 0, c_sky = 0;  // EXEC: exact tests run (test_sphere calls); samples finished in sky tiles
 
   // wave-uniform work queue: pixel slots [q_cur, q_end) of the tile this wave is handing out.
   // slot = (index of the tile in this rank's tile list) * 64 + (pixel within the 8x8 tile)
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   // Untamed rays take the compiler's division.
   auto test_sphere = [&](uint32_t i, float& closest, int& hit, unsigned long long any_untame) __attribute__((always_inline)) {
     const rn_divisor a_div = {a_lit, a_rcp, false};
+    if (EXEC) c_X++;
     {
       const f32x4 s = SMALL ? sph_lds[i] : a.sph_test[i];
       const float ocx = ox - s.x, ocy = oy - s.y, ocz = oz - s.z;
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         // STAGED LAUNCH: the unit of work is (pixel, frame k). The frame's colour goes to the staging buffer;
         // rt_combine_frames_kernel folds the frames into the image in order afterwards.
         f32x4 o; o.x = p0; o.y = p1; o.z = p2; o.w = 1.0f;
-        ca->staging[(size_t)k * ((size_t)ca->width * ca->height) + pix] = o;
+        ca->staging[((size_t)k * ca->my_tiles + my_tile) * 64u + ((uvp >> 13) & 56u) + (uvp & 7u)] = o;  // (v & 7) * 8 + (u & 7)
         done = true;
         last_frame = k + 1u == ca->n_frames;
       } else {
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           q_tile_new = ca->tile_order ? ca->tile_order[slot] : slot;
           // tile_masks[tile]: 0 = sky tile, else the spheres a primary ray of the tile can hit (SPLIT; all ones otherwise)
           q_mask_new = 0xffffffffu;
-          if (COUNT || !ca->tile_masks || (q_mask_new = __builtin_amdgcn_readfirstlane(ca->tile_masks[q_tile_new])) != 0u) break;
+          if ((COUNT && !SPLIT) || !ca->tile_masks || (q_mask_new = __builtin_amdgcn_readfirstlane(ca->tile_masks[q_tile_new])) != 0u) break;
           // ---- SKY TILE, finished right here by all 64 lanes (lane = pixel, no divergence; the lanes' own paths
           // wait): rt_tile_masks_kernel proved that every primary ray of this tile misses every sphere in the literal
           // arithmetic ("sky tiles"). Each sample is then get_random_ray's two draws and the miss
@@ -920,6 +924,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
             uint32_t srng = 0, q8 = 0;
             for (uint32_t kf = kf0; kf < kf1; ++kf) {
               srng = rng_step(sseed ^ (ca->frame_table ? ca->frame_table[kf].x : ca->seed_t0));  // initialize_rng (wgsl:254-263)
+              if (EXEC) { c_P++; c_N += ca->spp; c_M += ca->spp; c_sky += ca->spp; c_rand += 1u + 2u * ca->spp; }
               float ssx = 0.0f, ssy = 0.0f, ssz = 0.0f;
               for (uint32_t sm = 0; sm < ca->spp; ++sm) {
                 srng = rng_step(srng);  // px: does not reach the miss colour
@@ -943,7 +948,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
               }
               if (ca->staging) {
                 f32x4 o; o.x = p0; o.y = p1; o.z = p2; o.w = 1.0f;
-                ca->staging[(size_t)kf * ((size_t)ca->width * ca->height) + spix] = o;
+                ca->staging[((size_t)kf * ca->my_tiles + q_tile_new) * 64u + lane] = o;  // lane = (v & 7) * 8 + (u & 7)
               } else {
                 const float cw = ca->frame_table ? as_f32(ca->frame_table[kf].y) : ca->cw0;
                 q8 = combine_frame(b0, b1, b2, b3, p0, p1, p2, cw, combine_sum, accum_f32);
@@ -1056,6 +1061,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         start_ray(s0, s1);
         p1_ray unused;
         iters++;
+        if (EXEC) c_R++;
         ray_prelude(std::integral_constant<bool, false>{}, unused);
         cand = tmask;
         w_closest = RT_RAY_TMAX; w_hit = 0xffffffffu;
@@ -1114,6 +1120,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         RT_PROF_LANES(1);
         RT_PROF_BEGIN(1);
         iters++;
+        if (EXEC) { c_R++; c_T += n_spheres; }
         p1_ray p1q;
         ray_prelude(std::integral_constant<bool, true>{}, p1q);
         RT_PROF_END(1);
@@ -1147,6 +1154,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       if (state == ST_TEST) {
         p1_ray unused;
         iters++;
+        if (EXEC) c_R++;
         ray_prelude(std::integral_constant<bool, false>{}, unused);
         float closest = RT_RAY_TMAX;
         int hit = -1;
@@ -1214,7 +1222,10 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     const uint32_t vals[12] = {c_T, c_D, c_H, c_R, c_M, c_S, c_Sm, c_J, c_Sd, c_N, c_P, c_rand};
 #pragma unroll
     for (int i = 0; i < 12; ++i) atomicAdd(&ca->counters[i], (unsigned long long)vals[i]);
-    if (lane_id() == 0u) {
+    if (EXEC) {  // slots 12 / 13 carry the exact tests run and the samples finished in sky tiles (rt_hip.h, rt_enable_counters mode 2)
+      atomicAdd(&ca->counters[12], (unsigned long long)c_X);
+      atomicAdd(&ca->counters[13], (unsigned long long)c_sky);
+    } else if (lane_id() == 0u) {
       atomicAdd(&ca->counters[12], 64ull * c_wt);
       atomicAdd(&ca->counters[13], 64ull * c_wr);
     }
@@ -1230,7 +1241,9 @@ __global__ __launch_bounds__(256) void rt_combine_frames_kernel(const rt_kargs a
   const uint32_t tile = (pv >> 3) * a.tiles_x + (pu >> 3);
   if (tile % a.world != a.rank) return;
   const bool accum_f32 = (a.flags & RT_ACCUM_F32) != 0, combine_sum = (a.flags & RT_COMBINE_SUM) != 0;
-  const size_t pix = (size_t)pv * a.width + pu, npix = (size_t)a.width * a.height;
+  const size_t pix = (size_t)pv * a.width + pu;
+  // staging is indexed by this rank's own tiles: ((frame * my_tiles + tile slot) * 64 + pixel within the tile), slot = tile / world
+  const size_t sidx = (size_t)(tile / a.world) * 64u + (pv & 7u) * 8u + (pu & 7u), sstride = (size_t)a.my_tiles * 64u;
   float acc0, acc1, acc2, acc3;
   if (accum_f32) {
     const f32x4 c = reinterpret_cast<const f32x4*>(a.accum)[pix];
@@ -1242,7 +1255,7 @@ __global__ __launch_bounds__(256) void rt_combine_frames_kernel(const rt_kargs a
   }
   uint32_t q8 = 0;
   for (uint32_t k = 0; k < a.n_frames; ++k) {
-    const f32x4 p = a.staging[(size_t)k * npix + pix];
+    const f32x4 p = a.staging[(size_t)k * sstride + sidx];
     q8 = combine_frame(acc0, acc1, acc2, acc3, p.x, p.y, p.z, as_f32(a.frame_table[k].y), combine_sum, accum_f32);
   }
   if (accum_f32) {
@@ -1408,6 +1421,16 @@ __global__ __launch_bounds__(1024) void rt_tile_order_kernel(const uint32_t* __r
   }
 }
 
+// Frame table of a batched launch {bits(time) * 87189 + 189273 (wgsl:260), bits of cw = f32(frame) / f32(frame + 1) (wgsl:108)}
+// written on the device from time bits passed by value (rt_render_frames_static: nothing staged in host memory).
+struct rt_time_bits_arg { uint32_t bits[256]; };
+__global__ __launch_bounds__(256) void rt_frame_table_kernel(uint2* __restrict__ table, const rt_time_bits_arg tb, uint32_t first_frame, uint32_t n) {
+  const uint32_t i = threadIdx.x;
+  if (i >= n) return;
+  const float f = (float)(first_frame + i), g = (float)(first_frame + i + 1u);
+  table[i] = make_uint2(tb.bits[i] * 87189u + 189273u, as_u32(f / g));  // IEEE division (no fast-math in this file), as frame_cw() on the host
+}
+
 // RGBA8 view of a float4 accumulation image (rt_read_rgba8 on RT_ACCUM_F32 contexts)
 __global__ void rt_quantize_kernel(const f32x4* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1423,18 +1446,22 @@ hipError_t rt_launch_path_kernel(const rt_kargs& a, uint32_t n_waves, bool stric
   const dim3 grid(n_waves), block(64);
   // SPLIT needs what makes its primary section correct: candidate masks (<= 32 spheres) or lists (> RT_SMALL_MAX), no counting
   const bool small = a.n_spheres <= RT_SMALL_MAX;
-  if (split && (count || !a.tile_masks || (a.n_spheres > 32u && (small || !a.tile_lists)))) return hipErrorInvalidValue;
+  if (split && (!a.tile_masks || (a.n_spheres > 32u && (small || !a.tile_lists)))) return hipErrorInvalidValue;
   // SMALL variants while the scene fits their LDS arrays. The behind cull they carry in strict mode saves exact tests
   // for one more instruction per sphere test (measured: 20 spheres -3 %, 1024 spheres +2 %). Counting launches keep
   // every candidate: the oracle's D counts their discriminants.
   if (strict) {
-    if (count) hipLaunchKernelGGL((rt_path_kernel<true, true, false, false>), grid, block, 0, stream, a);
+    if (count && split && small) hipLaunchKernelGGL((rt_path_kernel<true, true, true, true>), grid, block, 0, stream, a);
+    else if (count && split) hipLaunchKernelGGL((rt_path_kernel<true, true, false, true>), grid, block, 0, stream, a);
+    else if (count) hipLaunchKernelGGL((rt_path_kernel<true, true, false, false>), grid, block, 0, stream, a);
     else if (split && small) hipLaunchKernelGGL((rt_path_kernel<true, false, true, true>), grid, block, 0, stream, a);
     else if (split) hipLaunchKernelGGL((rt_path_kernel<true, false, false, true>), grid, block, 0, stream, a);
     else if (small) hipLaunchKernelGGL((rt_path_kernel<true, false, true, false>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((rt_path_kernel<true, false, false, false>), grid, block, 0, stream, a);
   } else {
-    if (count) hipLaunchKernelGGL((rt_path_kernel<false, true, false, false>), grid, block, 0, stream, a);
+    if (count && split && small) hipLaunchKernelGGL((rt_path_kernel<false, true, true, true>), grid, block, 0, stream, a);
+    else if (count && split) hipLaunchKernelGGL((rt_path_kernel<false, true, false, true>), grid, block, 0, stream, a);
+    else if (count) hipLaunchKernelGGL((rt_path_kernel<false, true, false, false>), grid, block, 0, stream, a);
     else if (split && small) hipLaunchKernelGGL((rt_path_kernel<false, false, true, true>), grid, block, 0, stream, a);
     else if (split) hipLaunchKernelGGL((rt_path_kernel<false, false, false, true>), grid, block, 0, stream, a);
     else if (small) hipLaunchKernelGGL((rt_path_kernel<false, false, true, false>), grid, block, 0, stream, a);
@@ -1460,6 +1487,15 @@ hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, uint16_t* li
 hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t n, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+  return hipGetLastError();
+}
+
+hipError_t rt_launch_frame_table(uint2* table, const uint32_t* time_bits_host, uint32_t first_frame, uint32_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  if (n > 256u) return hipErrorInvalidValue;
+  rt_time_bits_arg tb{};
+  for (uint32_t i = 0; i < n; ++i) tb.bits[i] = time_bits_host[i];
+  hipLaunchKernelGGL(rt_frame_table_kernel, dim3(1), dim3(256), 0, stream, table, tb, first_frame, n);
   return hipGetLastError();
 }
 

@@ -139,6 +139,7 @@ class Raytracer:
         return out
 
     def enable_counters(self, on=True):
+        """True / 1: the reference algorithm's events; 2: the events the production launch executes (include/rt_hip.h)."""
         check(self._lib.rt_enable_counters(self._h, int(on)))
 
     def reset_counters(self):

@@ -33,7 +33,7 @@ def _worker(rank, world, port, mode, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from raytracer_amd import dist as rdist
 
-    W, H, spp, frames = 80, 64, 2, 6
+    W, H, spp, frames = 80, 64, 2, (6 if world < 8 else 16)
     spheres, mats = scenes.default_scene(1)
     cam = scenes.camera_raw(W, H, spp=spp, frames=frames)
     try:
@@ -80,7 +80,7 @@ def _worker(rank, world, port, mode, q):
 
 
 @pytest.mark.parametrize("mode,world", [("tiles_f32", 2), ("tiles_rgba8", 2), ("frames", 2), ("tiles_f32_gather", 2),
-                                        ("tiles_rgba8_gather", 2), ("tiles_f32_gather", 3)])
+                                        ("tiles_rgba8_gather", 2), ("tiles_f32_gather", 3), ("tiles_f32_gather", 8), ("frames", 8)])
 def test_two_rank_combine(mode, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -89,7 +89,7 @@ def test_two_rank_combine(mode, world):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(240)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
 

@@ -14,9 +14,11 @@ import scenes
 pytestmark = pytest.mark.gpu
 
 
-def _render(R, static, W, H, flags, spheres, mats, spp, frames, calls):
+def _render(R, static, W, H, flags, spheres, mats, spp, frames, calls, partition=None):
     """`calls` = frame counts of consecutive render calls on one context. Returns (rgba8, f32 or None, rng)."""
     rt = R.Raytracer(W, H, flags)
+    if partition:
+        rt.set_partition(*partition)
     rt.set_scene(spheres, mats)
     rt.enable_rng_capture(True)
     rt.set_camera(scenes.camera_raw(W, H, spp=spp, frames=frames))
@@ -82,4 +84,116 @@ def test_static_entry_point_rejects_what_it_cannot_hold():
     rt.sync()
     rt.render_frames_static(O.time_bits_table(2))  # fine now
     rt.sync()
+    rt.close()
+
+
+def test_static_entry_point_allocates_no_device_memory_big_scene_and_partition():
+    """check the property the entry point exists for. After one warm-up call (the first launch of a kernel loads
+    its code object), free device memory must not move over further static calls - on the MASK path (20 spheres), on the
+    classic path of a scene above 64 spheres (all-ones masks from the scratch, no lists) and under a tile partition."""
+    import torch
+
+    import raytracer_amd as R
+
+    cases = [dict(W=272, H=208, flags=R.RT_ACCUM_F32 | R.RT_SHADE_CHECKER, spp=2, frames=64, scene=scenes.random_bunch(20, 3, 3), partition=None),
+             dict(W=160, H=128, flags=R.RT_ACCUM_F32, spp=2, frames=64, scene=scenes.random_bunch(200, 4, 16), partition=None),
+             dict(W=272, H=208, flags=R.RT_ACCUM_RGBA8, spp=2, frames=64, scene=scenes.default_scene(1), partition=(1, 3))]
+    for c in cases:
+        sp, mt = c["scene"]
+        rt = R.Raytracer(c["W"], c["H"], c["flags"])
+        if c["partition"]:
+            rt.set_partition(*c["partition"])
+        rt.set_scene(sp, mt)
+        rt.enable_rng_capture(True)
+        rt.set_camera(scenes.camera_raw(c["W"], c["H"], spp=c["spp"], frames=c["frames"]))
+        tb = O.time_bits_table(c["frames"])
+        rt.render_frames_static(tb[:3])  # warm-up
+        rt.sync()
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        at = 3
+        for n in (1, 7, 2, 5):
+            rt.render_frames_static(tb[at:at + n])
+            at += n
+        rt.sync()
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0, "a static call changed the free device memory"
+        got = (rt.read_rgba8(), rt.read_accum_f32() if c["flags"] & R.RT_ACCUM_F32 else None, rt.read_rng_state())
+        rt.close()
+        _same(got, _render(R, False, c["W"], c["H"], c["flags"], sp, mt, c["spp"], c["frames"], [at], partition=c["partition"]))
+
+
+def test_two_contexts_alternate_static_calls_without_syncing():
+    """every context of a GPU shares that GPU's scratch and has a stream of its own; the library orders the
+    calls on the device (one event per GPU), so alternating calls of two contexts need no rt_sync in between."""
+    import raytracer_amd as R
+
+    a = dict(W=272, H=208, flags=R.RT_ACCUM_F32 | R.RT_SHADE_CHECKER, spp=3, frames=12, scene=scenes.random_bunch(20, 3, 3))
+    b = dict(W=208, H=144, flags=R.RT_ACCUM_RGBA8, spp=2, frames=12, scene=scenes.default_scene(1))
+    ctxs = []
+    for c in (a, b):
+        rt = R.Raytracer(c["W"], c["H"], c["flags"])
+        rt.set_scene(*c["scene"])
+        rt.enable_rng_capture(True)
+        rt.set_camera(scenes.camera_raw(c["W"], c["H"], spp=c["spp"], frames=c["frames"]))
+        ctxs.append(rt)
+    tb = O.time_bits_table(12)
+    for at in range(0, 12, 3):  # A, B, A, B, ... : four calls each, none waited for
+        for rt in ctxs:
+            rt.render_frames_static(tb[at:at + 3])
+    for c, rt in zip((a, b), ctxs):
+        rt.sync()
+        got = (rt.read_rgba8(), rt.read_accum_f32() if c["flags"] & R.RT_ACCUM_F32 else None, rt.read_rng_state())
+        rt.close()
+        _same(got, _render(R, False, c["W"], c["H"], c["flags"], c["scene"][0], c["scene"][1], c["spp"], c["frames"], [12]))
+
+
+def test_static_entry_point_under_graph_capture_replays_with_its_own_frame_table():
+    """the header promises that rt_render_frames_static can be captured. Capture a 4-frame call on a caller's
+    stream (nothing runs), replay it, compare with rt_render_frames; then clear the image, make ANOTHER static call on a
+    second context (which rewrites the scratch's frame table) and replay again: the graph carries its own table."""
+    import torch
+
+    import raytracer_amd as R
+
+    W, H, spp = 272, 208, 3
+    sp, mt = scenes.random_bunch(20, 3, 3)
+    flags = R.RT_ACCUM_F32 | R.RT_SHADE_CHECKER
+    tb = O.time_bits_table(16)
+    want = _render(R, False, W, H, flags, sp, mt, spp, 16, [4])
+
+    rt = R.Raytracer(W, H, flags)
+    rt.set_scene(sp, mt)
+    rt.enable_rng_capture(True)
+    cam = scenes.camera_raw(W, H, spp=spp, frames=16)
+    rt.set_camera(cam)
+    rt.render_frames_static(tb[:4])  # warm-up outside the capture (code objects load on first launch)
+    rt.sync()
+    rt.clear()
+    rt.sync()
+    cam["current_frame"] = 0
+    rt.set_camera(cam)
+    stream = torch.cuda.Stream()
+    rt.set_stream(stream.cuda_stream)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        rt.render_frames_static(tb[:4])
+    torch.cuda.synchronize()
+    assert not rt.read_accum_f32().any(), "capturing must not run anything"
+    graph.replay()
+    torch.cuda.synchronize()
+    _same((rt.read_rgba8(), rt.read_accum_f32(), rt.read_rng_state()), want)
+
+    other = R.Raytracer(96, 64, R.RT_ACCUM_RGBA8)  # another user of this GPU's scratch: different frames, sizes, table
+    other.set_scene(*scenes.default_scene(1))
+    other.set_camera(scenes.camera_raw(96, 64, spp=1, frames=16))
+    other.render_frames_static(tb[8:16])
+    other.sync()
+    other.close()
+    rt.clear()
+    rt.sync()
+    graph.replay()
+    torch.cuda.synchronize()
+    _same((rt.read_rgba8(), rt.read_accum_f32(), rt.read_rng_state()), want)
+    rt.set_stream(0)
     rt.close()

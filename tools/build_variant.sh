@@ -4,7 +4,7 @@
 set -e
 tag=$1; shift
 cd "$(dirname "$0")/../raytracer_amd/csrc"
-F="--offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -I../../include -I."
+F="--offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -std=c++17 -I../../include -I."
 mkdir -p ../../build_variants /tmp/bv_$tag
 /opt/rocm/bin/hipcc $F "$@" -c rt_kernels.hip -o /tmp/bv_$tag/rt_kernels.o
 /opt/rocm/bin/hipcc $F "$@" -x hip -c rt_api.cpp -o /tmp/bv_$tag/rt_api.o

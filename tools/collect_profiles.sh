@@ -9,6 +9,7 @@ for d in gpurun_out/prof_${prefix}_*; do
   cp "$(ls "$d"/trace/*/*kernel_stats.csv | head -1)" profiles/${tag}_kernel_stats.csv
   cm=${tag#${prefix}_}                              # <config>_<math>
   [ -f "$d/traffic.json" ] && cp "$d/traffic.json" profiles/traffic_${cm}.json
+  [ -f "$d/valu_busy.json" ] && cp "$d/valu_busy.json" profiles/valu_busy_${cm}.json
 done
 for f in section_profile.log section_single.md section_lanes.log section_hist.log; do
   [ -f gpurun_out/$f ] && cp gpurun_out/$f profiles/${prefix}_$f

@@ -43,3 +43,21 @@ for k in sums:
              "rule": "RDREQ x 128 B + WRREQ x 64 B (separate --pmc pass, TCC_EA0_RDREQ_sum / TCC_EA0_WRREQ_sum), median launch"}
         json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
         print("traffic:", t)
+
+# VALUBusy of the path kernel (profiles/r3_valu_ceiling.txt): windows = SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2 (one 4-cycle
+# issue window per instruction, minus the instructions that rode as the second of a window), against SIMDs x shader cycles
+# (GRBM_GUI_ACTIVE is summed over the 8 XCDs). bench.py quotes this file as `roofline.valu_busy` with its source.
+for k in sums:
+    need = ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU2", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU")
+    if re.search(r"rt_path_kernel<(true|false), false", k) and all(n in sums[k] for n in need):
+        m = {n: statistics.median(each[k][n]) for n in need}
+        simds = int(os.environ.get("PROF_SIMDS", "1024"))  # 256 CUs x 4
+        cycles = m["GRBM_GUI_ACTIVE"] / 8.0
+        v = {"kernel": k, "valu_busy": round(4.0 * (m["SQ_ACTIVE_INST_VALU"] - m["SQ_ACTIVE_INST_VALU2"]) / (simds * cycles), 4),
+             "valu2_share": round(m["SQ_ACTIVE_INST_VALU2"] / m["SQ_INSTS_VALU"], 4),
+             "lane_utilisation": round(m["SQ_THREAD_CYCLES_VALU"] / m["SQ_INSTS_VALU"] / 64.0, 4),
+             "cycles_per_valu_instruction_and_simd": round(simds * cycles / m["SQ_INSTS_VALU"], 3),
+             "shader_cycles_per_launch": cycles, "frames_per_launch": int(os.environ.get("PROF_FRAMES_PER_LAUNCH", "1")),
+             "rule": "4 x (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), separate --pmc passes, median launch"}
+        json.dump(v, open(os.path.join(out, "valu_busy.json"), "w"), indent=1)
+        print("valu_busy:", v)
