@@ -18,11 +18,19 @@ def run(name, W, H, spp, scene, shade, math):
     rt = R.Raytracer(W, H, R.RT_ACCUM_F32 | shade | math)
     rt.set_scene(sp, mt)
     cam = scenes.camera_raw(W, H, spp=spp, frames=1000)
-    tb = O.time_bits_table(4)
+    batch = int(os.environ.get("SECTION_BATCH", "1"))  # passes per launch (the bench's launches hold 20)
+    tb = O.time_bits_table(3 * batch + 1)
     for i in range(3):  # third launch is measured (tile order settled)
         rt.reset_counters()
-        cam["current_frame"] = i
-        rt.set_camera(cam); rt.set_time(int(tb[i])); rt.compute(); rt.sync()
+        cam["current_frame"] = i * batch
+        rt.set_camera(cam)
+        if batch > 1:
+            rt.render_frames(tb[i * batch:(i + 1) * batch])
+        else:
+            rt.set_time(int(tb[i])); rt.compute()
+        rt.sync()
+    if batch > 1:
+        name = f"{name} ({batch}-pass launch)"
     c = rt.counters()
     life = c["S"]; iters = c["Sm"]
     only = os.environ.get("SECTION_ONLY")
