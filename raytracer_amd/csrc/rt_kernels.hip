@@ -110,13 +110,30 @@ __device__ __forceinline__ float dot_fast(float ax, float ay, float az, float bx
 // the compiler's own expansion without its denormal pre-scaling and class fix-up: v_sqrt_f32 is
 // within 1 ulp, and the two FMA residuals pick the correctly rounded neighbour. Smaller x (0,
 // denormals, negatives) takes the generic path.
+#ifndef RT_SQRT_SIGNS
+#define RT_SQRT_SIGNS 1
+#endif
+#ifndef RT_ROOT2_LAZY
+#define RT_ROOT2_LAZY 1
+#endif
 __device__ __forceinline__ float sqrt_rn(float x) {
   const float s = __builtin_amdgcn_sqrtf(x);
+#if RT_SQRT_SIGNS
+  // The same decision without compares and selects (two v_cmp + two v_cndmask + the wait states between them): with
+  // nrd = dn s - x and nru = up s - x (signs exact: an FMA rounds once, and an exact zero is +0), the result is
+  // dn when nrd >= 0, s when nrd < 0 <= nru, up when nru < 0 (then nrd < 0 too) = dn + sign bit(nrd) + sign bit(nru)
+  // in units in the last place. +inf and NaN (whose residuals are NaN, of either sign) join the rare path.
+  const uint32_t dnb = as_u32(s) - 1u;
+  const float nrd = __builtin_fmaf(as_f32(dnb), s, -x), nru = __builtin_fmaf(as_f32(as_u32(s) + 1u), s, -x);
+  float r = as_f32(dnb + (as_u32(nrd) >> 31) + (as_u32(nru) >> 31));
+  const bool rare = as_u32(x) - 0x0f800000u >= 0x70000000u;  // not in [2^-96, +inf)
+#else
   const float dn = as_f32(as_u32(s) - 1u), up = as_f32(as_u32(s) + 1u);
   const float rd = __builtin_fmaf(-dn, s, x), ru = __builtin_fmaf(-up, s, x);
   float r = rd <= 0.0f ? dn : s;
   r = ru > 0.0f ? up : r;
   const bool rare = x < 0x1p-96f;
+#endif
   if (RT_RARELY(rare)) {
     if (rare) r = __builtin_sqrtf(x);
   }
@@ -211,12 +228,40 @@ __device__ __forceinline__ uint32_t phase1_pair(uint32_t missbits, f32x2 cx, f32
   missbits = __builtin_amdgcn_alignbit(missbits, key0, 31);  // (missbits << 1) | sign
   return __builtin_amdgcn_alignbit(missbits, key1, 31);
 }
-// spheres base..base+cnt_pad-1 (base, cnt_pad multiples of 4): one s_load_dwordx16 per four spheres
+// SCALAR FORM (the small-scene variants, round 3): the same eight FMAs per sphere as plain v_fma_f32 / v_fmac_f32 with the sphere
+// constant as the scalar operand - twice the instructions of the packed form, but of the class that shares its 4-cycle issue
+// window with another wave's plain FP32 / integer instruction, where v_pk_fma_f32 issues alone (profiles/r3_valu_ceiling.txt,
+// classes S and X). Same operations in the same order as the packed form: the same bits. C3 strict -4.5 %, C2 -1 %; the
+// 1024-sphere scene, whose waves are all in phase 1 at once and have nothing to pair with, +14 % - it keeps the packed form.
+#ifndef RT_P1_SCALAR
+#define RT_P1_SCALAR 1
+#endif
 template <bool CULL>
+__device__ __forceinline__ uint32_t phase1_one(uint32_t missbits, float cx, float cy, float cz, float kk, const p1_ray& q) {
+  float nhb = __builtin_fmaf(cz, q.dz_nod.x, q.dz_nod.y);
+  nhb = __builtin_fmaf(cy, q.dx_dy.y, nhb);
+  nhb = __builtin_fmaf(cx, q.dx_dy.x, nhb);
+  float w = __builtin_fmaf(kk, q.na_nA.x, q.na_nA.y);
+  w = __builtin_fmaf(cx, q.Px_Py.x, w);
+  w = __builtin_fmaf(cy, q.Px_Py.y, w);
+  w = __builtin_fmaf(cz, q.Pz_0.x, w);
+  const float test = __builtin_fmaf(nhb, nhb, w);
+  const uint32_t key = CULL ? __builtin_amdgcn_bitop3_b32(as_u32(nhb), as_u32(w), as_u32(test), 0xEA) : as_u32(test);
+  return __builtin_amdgcn_alignbit(missbits, key, 31);
+}
+// spheres base..base+cnt_pad-1 (base, cnt_pad multiples of 4): one s_load_dwordx16 per four spheres
+template <bool CULL, bool SCALAR>
 __device__ __forceinline__ uint32_t phase1_missbits(const_f32x16_ptr sph_p1, uint32_t base, uint32_t cnt_pad, const p1_ray& q) {
   uint32_t missbits = 0xffffffffu;
 #define RT_P1_FOUR(s)                                                                                                          \
   do {                                                                                                                         \
+    if (SCALAR) {                                                                                                              \
+      missbits = phase1_one<CULL>(missbits, s[0], s[2], s[4], s[6], q);                                                        \
+      missbits = phase1_one<CULL>(missbits, s[1], s[3], s[5], s[7], q);                                                        \
+      missbits = phase1_one<CULL>(missbits, s[8], s[10], s[12], s[14], q);                                                     \
+      missbits = phase1_one<CULL>(missbits, s[9], s[11], s[13], s[15], q);                                                     \
+      break;                                                                                                                   \
+    }                                                                                                                          \
     missbits = phase1_pair<CULL>(missbits, __builtin_shufflevector(s, s, 0, 1), __builtin_shufflevector(s, s, 2, 3),           \
                                  __builtin_shufflevector(s, s, 4, 5), __builtin_shufflevector(s, s, 6, 7), q);                 \
     missbits = phase1_pair<CULL>(missbits, __builtin_shufflevector(s, s, 8, 9), __builtin_shufflevector(s, s, 10, 11),         \
@@ -349,6 +394,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   // behind cull: strict small-scene launches (fewer exact tests), and every SPLIT launch (there a bounce ray without
   // candidates is finished on the spot, so candidates that only fall to the exact test cost a loop iteration)
   constexpr bool QUEUE = STRICT && !SMALL && (!COUNT || SPLIT);  // the general trace collects a ray's candidates over all blocks before the exact tests
+  constexpr bool P1S = SMALL && RT_P1_SCALAR;  // phase 1 in the scalar-operand form (see phase1_one)
   constexpr bool CULL = SMALL && (STRICT || SPLIT);  // (the 1024-sphere scene loses 2 % with it: one more instruction per sphere)
   // The lane index is recomputed where the cold code needs it (two v_mbcnt behind a compiler barrier) instead of
   // living in a register across the hot loop: at 72 registers that one value was the last spill.
@@ -519,10 +565,24 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           const float sq = sqrt_rn(disc);
           float root = div_known(-hb - sq, a_div, !tame, any_untame);
           bool ok = true;
+#if RT_ROOT2_LAZY
+          // The second root is only worth a division when the first one lies behind tmin: for a tame ray (a_lit > 0,
+          // hb and sq finite, sq >= +0) fl(-hb + sq) >= fl(-hb - sq) and the correctly rounded quotients by a_lit keep
+          // that order, so `closest <= root1` implies `closest <= root2` - hit_sphere (wgsl:214-222) rejects both.
+          const bool behind1 = root <= RT_RAY_TMIN;
+          if (behind1 || closest <= root) {
+            ok = false;
+            if (behind1 || !tame) {
+              root = div_known(-hb + sq, a_div, !tame, any_untame);
+              ok = !(root <= RT_RAY_TMIN || closest <= root);
+            }
+          }
+#else
           if (root <= RT_RAY_TMIN || closest <= root) {
             root = div_known(-hb + sq, a_div, !tame, any_untame);
             if (root <= RT_RAY_TMIN || closest <= root) ok = false;
           }
+#endif
           if (ok) { closest = root; hit = (int)i; }
         }
       } else {
@@ -703,7 +763,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         // bit (cnt_pad-1-j) of `missbits` = sign of sphere (base+j)'s value (1 = certain miss)
         const uint32_t cnt_pad = (cnt + 3u) & ~3u;
         RT_PROF_BEGIN(2);
-        const uint32_t missbits = phase1_missbits<CULL>(sph_p1, base, cnt_pad, p1q);
+        const uint32_t missbits = phase1_missbits<CULL, P1S>(sph_p1, base, cnt_pad, p1q);
 #if RT_PROFILE_SECTIONS
         asm volatile("" :: "v"(missbits));  // keep the loop inside the timed region
 #endif
@@ -1125,7 +1185,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         ray_prelude(std::integral_constant<bool, true>{}, p1q);
         RT_PROF_END(1);
         RT_PROF_BEGIN(2);
-        const uint32_t missbits = phase1_missbits<CULL>(sph_p1, 0u, n_pad32, p1q);
+        const uint32_t missbits = phase1_missbits<CULL, P1S>(sph_p1, 0u, n_pad32, p1q);
         cand = (~missbits | (tame ? 0u : 0xffffffffu)) & valid32 & ~(own_sphere_drop() ? 1u << (n_pad32 - 1u - own) : 0u);
         w_closest = RT_RAY_TMAX; w_hit = 0xffffffffu;  // (own is dead from here on: w_hit shares its register)
         state = ST_TEST;
