@@ -128,6 +128,7 @@ struct rt_ctx {
   size_t staging_bytes = 0;
   size_t stage_cap = 0;       // largest staging buffer this context allocates (stage_limit(); 0 = not asked yet)
   int use_staging = 1;        // env RT_STAGED_FRAMES=0 keeps batched launches pixel-sequential
+  int frame_group = 0;        // env RT_FRAME_GROUP: largest frame group of a staged launch (0 = RT_FRAME_GROUP_MAX)
   // deferred passes: rt_compute records (frame, time bits); the passes run as ONE batched launch when `defer_max` of
   // them wait or when any call observes or changes what they depend on (flush_pending)
   std::vector<uint32_t> pend_frames, pend_time;
@@ -162,6 +163,8 @@ constexpr uint32_t RT_ORDER_REFRESH = 32;  // launches between two measurements 
 constexpr uint64_t RT_STAGE_BELOW = 32;    // batches are staged per frame when a rank has fewer tiles per wave than this
 constexpr uint32_t RT_STAGE_MIN_SPP = 4;   // below that a (tile, frame) unit is too little work for its hand-out (C1: 1 spp got slower)
 constexpr size_t RT_STAGE_MAX_BYTES = (size_t)4 << 30;  // largest staging buffer a context allocates
+constexpr uint32_t RT_FRAME_GROUP_MAX = 2u;     // staged launches: frames per unit of work (env RT_FRAME_GROUP overrides; 1 = a unit per frame). C2: 1 / 2 / 4 = 56.4 / 58.1 / 57.8 Gsamples/s, C4 (dear pixels: tails): 5.23 / 5.22 / 4.85 (profiles/r3_sweep_groups.log)
+constexpr uint64_t RT_GROUP_MIN_UNITS = 16u;    // ... while every resident wave keeps at least this many units
 
 // Largest staging buffer a context may allocate: RT_STAGE_MAX_BYTES, and never more than a quarter of the device memory
 // that is free right now (a plain rt_compute loop must not take gigabytes inside an observer call unasked).
@@ -239,6 +242,8 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // RT_STAGE_BELOW tiles per wave (and at least RT_STAGE_MIN_SPP samples per pixel), the unit of work becomes (tile, frame): the frames' colours go to a
   // staging buffer and a second kernel folds them into the image in order (same arithmetic, bit-identical).
   a.n_units = my_tiles;
+  a.frame_group = 1u;
+  a.n_groups = n_frames;
   const size_t stage_bytes = (size_t)n_frames * my_tiles * 64u * sizeof(rt_f32x4);  // the rank's own tiles only
   if (!scratch && ctx->use_staging && n_frames > 1 && time_table_dev && a.spp >= RT_STAGE_MIN_SPP && (uint64_t)my_tiles < RT_STAGE_BELOW * resident &&
       stage_bytes <= stage_limit(ctx) && (uint64_t)my_tiles * n_frames < 0xffffffffull / 64u) {
@@ -257,7 +262,16 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     }
     if (ctx->staging) {
       a.staging = ctx->staging;
-      a.n_units = my_tiles * n_frames;
+      // FRAME GROUPS: a unit is (tile, g consecutive frames), g a power of two: a lane keeps the pixel it is handed for
+      // g frames (one pixel hand-out and 1/g tile fetch per g frame ends), as long as every resident wave still gets
+      // RT_GROUP_MIN_UNITS units of work - the staging rule exists because few units per wave mean long tails.
+      uint32_t g = 1u;
+      const bool forced = ctx->frame_group > 0;  // env RT_FRAME_GROUP: that group size (rounded down to a power of two), whatever the launch shape
+      const uint32_t g_max = forced ? (uint32_t)ctx->frame_group : RT_FRAME_GROUP_MAX;
+      while (g * 2u <= g_max && g * 2u <= n_frames && (forced || (uint64_t)my_tiles * ((n_frames + 2u * g - 1u) / (2u * g)) >= RT_GROUP_MIN_UNITS * resident)) g *= 2u;
+      a.frame_group = g;
+      a.n_groups = (n_frames + g - 1u) / g;
+      a.n_units = my_tiles * a.n_groups;
     }
   }
   // Launch width: 6 waves per SIMD are resident (<= 80 VGPRs); the SMALL variants fit 7 (<= 72 VGPRs), which pays
@@ -466,6 +480,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e3 = std::getenv("RT_BATCH_LANES")) c->batch_lanes = std::atoi(e3);
   if (const char* e4 = std::getenv("RT_TILE_ORDER")) c->use_order = std::atoi(e4);
   if (const char* e5 = std::getenv("RT_STAGED_FRAMES")) c->use_staging = std::atoi(e5);
+  if (const char* e6 = std::getenv("RT_FRAME_GROUP")) c->frame_group = std::atoi(e6);
   if (const char* e6 = std::getenv("RT_SKY_TILES")) c->use_sky = std::atoi(e6);
   if (const char* e7 = std::getenv("RT_DEFER_FRAMES")) c->defer_max = std::atoi(e7);
   if (const char* e8 = std::getenv("RT_SPLIT")) c->use_split = std::atoi(e8);

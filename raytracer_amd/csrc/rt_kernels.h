@@ -22,7 +22,7 @@ struct rt_kargs {
   uint32_t tiles_x, n_tiles;  // 8x8 tiles over the covered area
   uint32_t rank, world;     // tile t belongs to this launch iff t % world == rank
   uint32_t my_tiles;        // number of tiles of this rank: tile = j * world + rank, j < my_tiles
-  uint32_t n_units;         // queue length: my_tiles, or my_tiles * n_frames in a staged launch
+  uint32_t n_units;         // queue length: my_tiles, or my_tiles * n_groups in a staged launch
   uint32_t reject_tries;    // rejection-sampling rounds per loop iteration (>= 1)
   uint32_t spp;
   uint32_t first_frame, n_frames;
@@ -50,6 +50,7 @@ struct rt_kargs {
   const uint16_t* tile_lists;    // optional, scenes of > 32 spheres, 16 x u16 per tile of this rank: [0] = number of spheres a
                                  // primary ray of the tile can hit (<= 15; 0xffff = more, or rays not provably tame), [1..] their
                                  // indices in ascending order
+  uint32_t frame_group, n_groups;  // staged launch: a unit of work is (tile, frame_group consecutive frames: a power of two), n_groups = ceil(n_frames / frame_group)
 };
 
 // n_waves persistent single-wave workgroups pull tiles from a.queue until a.my_tiles are handed out

@@ -720,6 +720,25 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   };
   const uint32_t valid32 = (n_pad32 >= 32u ? 0xffffffffu : (1u << n_pad32) - 1u) & ~((1u << (n_pad32 - (n_spheres < 32u ? n_spheres : 32u) & 31u)) - 1u);
 
+  // PROBE (-DRT_PROBE_BPERMUTE=1, tools/r3_ab.sh): what moving a ray to another lane costs. The seven dwords phase 1 needs of a
+  // ray (o, d, own) go through ds_bpermute_b32 with the lane's own index - the identity, so every result bit stays - in front
+  // of phase 1: the floor under the cost of ANY cross-lane compaction of the READY lanes (which also needs the destination
+  // lanes - a ballot and two v_mbcnt - and the way back, or the rest of the path's state). profiles/r3_compaction_probe.md.
+#ifndef RT_PROBE_BPERMUTE
+#define RT_PROBE_BPERMUTE 0
+#endif
+  auto probe_bpermute = [&]() __attribute__((always_inline)) {
+#if RT_PROBE_BPERMUTE
+    const int self = (int)(lane_id() << 2);
+    ox = as_f32((uint32_t)__builtin_amdgcn_ds_bpermute(self, (int)as_u32(ox)));
+    oy = as_f32((uint32_t)__builtin_amdgcn_ds_bpermute(self, (int)as_u32(oy)));
+    oz = as_f32((uint32_t)__builtin_amdgcn_ds_bpermute(self, (int)as_u32(oz)));
+    dx = as_f32((uint32_t)__builtin_amdgcn_ds_bpermute(self, (int)as_u32(dx)));
+    dy = as_f32((uint32_t)__builtin_amdgcn_ds_bpermute(self, (int)as_u32(dy)));
+    dz = as_f32((uint32_t)__builtin_amdgcn_ds_bpermute(self, (int)as_u32(dz)));
+    own = (uint32_t)__builtin_amdgcn_ds_bpermute(self, (int)own);
+#endif
+  };
   // [C] the general trace: prelude, then per block of 32 spheres phase 1 and the walk of its candidates, then miss or scatter
   auto trace_general = [&]() __attribute__((always_inline)) {
     if (COUNT && __ballot(state == ST_READY)) c_wt++;
@@ -730,6 +749,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       float closest = RT_RAY_TMAX;
       int hit = -1;
       p1_ray p1q;
+      probe_bpermute();
       ray_prelude(std::integral_constant<bool, true>{}, p1q);
       const unsigned long long any_untame = __ballot(!tame);
       const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
@@ -855,10 +875,13 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       if (ca->staging) {
         // STAGED LAUNCH: the unit of work is (pixel, frame k). The frame's colour goes to the staging buffer;
         // rt_combine_frames_kernel folds the frames into the image in order afterwards.
+        // The lane keeps its pixel for the frames of the unit's group (frame_group, a power of two): the next frame of the
+        // group starts right below, without a pixel hand-out.
         f32x4 o; o.x = p0; o.y = p1; o.z = p2; o.w = 1.0f;
         ca->staging[((size_t)k * ca->my_tiles + my_tile) * 64u + ((uvp >> 13) & 56u) + (uvp & 7u)] = o;  // (v & 7) * 8 + (u & 7)
-        done = true;
-        last_frame = k + 1u == ca->n_frames;
+        k++;
+        last_frame = k == ca->n_frames;
+        done = last_frame || (k & (ca->frame_group - 1u)) == 0u;
       } else {
         // The accumulation pixel is read, combined and written back HERE, per frame (it belongs to this lane for the
         // whole launch, so the read sees the lane's own previous write): carrying it in four registers across the
@@ -948,7 +971,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           if (base == 0xffffffffu) break;
           uint32_t slot = base;
           q_frame_new = 0;
-          if (ca->staging) { slot = base / ca->n_frames; q_frame_new = base - slot * ca->n_frames; }
+          if (ca->staging) { slot = base / ca->n_groups; q_frame_new = (base - slot * ca->n_groups) * ca->frame_group; }
           q_tile_new = ca->tile_order ? ca->tile_order[slot] : slot;
           // tile_masks[tile]: 0 = sky tile, else the spheres a primary ray of the tile can hit (SPLIT; all ones otherwise)
           q_mask_new = 0xffffffffu;
@@ -980,7 +1003,8 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
               b0 = unorm8_to_f32(q & 255u); b1 = unorm8_to_f32((q >> 8) & 255u);
               b2 = unorm8_to_f32((q >> 16) & 255u); b3 = unorm8_to_f32(q >> 24);
             }
-            const uint32_t kf0 = ca->staging ? q_frame_new : 0u, kf1 = ca->staging ? q_frame_new + 1u : ca->n_frames;
+            const uint32_t kf0 = ca->staging ? q_frame_new : 0u;
+            const uint32_t kf1 = ca->staging && q_frame_new + ca->frame_group < ca->n_frames ? q_frame_new + ca->frame_group : ca->n_frames;
             uint32_t srng = 0, q8 = 0;
             for (uint32_t kf = kf0; kf < kf1; ++kf) {
               srng = rng_step(sseed ^ (ca->frame_table ? ca->frame_table[kf].x : ca->seed_t0));  // initialize_rng (wgsl:254-263)
@@ -1182,6 +1206,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         iters++;
         if (EXEC) { c_R++; c_T += n_spheres; }
         p1_ray p1q;
+        probe_bpermute();
         ray_prelude(std::integral_constant<bool, true>{}, p1q);
         RT_PROF_END(1);
         RT_PROF_BEGIN(2);

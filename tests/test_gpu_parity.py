@@ -598,6 +598,29 @@ def test_staged_batches_equal_pixel_sequential_batches_and_the_oracle(flags, mon
             rt.close()
 
 
+@pytest.mark.parametrize("group", ["2", "4", "8"])
+@pytest.mark.parametrize("flags,scene", [(O.ACCUM_F32, "default"), (0, "default"), (O.ACCUM_F32 | O.SHADE_CHECKER, "bunch20"), (O.ACCUM_F32, "bunch300")],
+                         ids=["f32_default", "rgba8_default", "f32_checker20", "f32_300"])
+def test_frame_groups_of_staged_batches_change_no_bit(group, flags, scene, monkeypatch):
+    """Staged launches hand a lane its pixel for a GROUP of consecutive frames (RT_FRAME_GROUP, a power of two; the default
+    picks it from the launch shape and stays at 1 for images this small, hence the override). 7 frames: the last group is
+    short for every group size; sky tiles (whole-wave branch) and traced tiles, the MASK, classic and LIST shapes, a partition."""
+    R = _rt()
+    W, H, spp, frames = 120, 72, 4, 7
+    spheres, mats = scenes.default_scene(1) if scene == "default" else scenes.random_bunch(int(scene[5:]), 3, 3)
+    cam = scenes.camera_raw(W, H, spp=spp, frames=frames)
+    monkeypatch.setenv("RT_FRAME_GROUP", group)
+    for rank, world in ((0, 1), (2, 3)):
+        img = O.OracleImage(W, H, flags)
+        O.render(img, spheres, mats, cam, 0, frames, rank=rank, world=world)
+        rt = _run_gpu(R, W, H, flags, spheres, mats, cam, frames, batched=True, rank=rank, world=world)
+        assert np.array_equal(rt.read_rng_state(), img.rng), (rank, world)
+        if flags & O.ACCUM_F32:
+            assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32)), (rank, world)
+        assert np.array_equal(rt.read_rgba8(), img.view_rgba8()), (rank, world)
+        rt.close()
+
+
 def _render_state(R, W, H, flags, spheres, mats, cam, frames, batched, rank=0, world=1):
     rt = _run_gpu(R, W, H, flags, spheres, mats, cam, frames, batched=batched, rank=rank, world=world)
     out = (rt.read_rng_state().copy(), rt.read_accum_f32().view(np.uint32).copy() if flags & O.ACCUM_F32 else None,
@@ -946,7 +969,7 @@ def test_sky_tiles_are_off_for_a_non_finite_camera(monkeypatch):
 
 @pytest.mark.parametrize("knob,value", [("RT_REJECT_TRIES", "1"), ("RT_REJECT_TRIES", "5"), ("RT_BATCH_LANES", "1"), ("RT_BATCH_LANES", "9"),
                                         ("RT_WAVES_PER_CU", "3"), ("RT_WAVES_PER_CU", "32"), ("RT_STAGED_FRAMES", "0"),
-                                        ("RT_TILE_ORDER", "0"), ("RT_DEFER_FRAMES", "3"), ("RT_SPLIT", "0"), ("RT_SKY_TILES", "0")])
+                                        ("RT_TILE_ORDER", "0"), ("RT_DEFER_FRAMES", "3"), ("RT_SPLIT", "0"), ("RT_SKY_TILES", "0"), ("RT_FRAME_GROUP", "4")])
 def test_launch_knobs_change_no_bit(knob, value, monkeypatch):
     """Launch width, rejection rounds per iteration, parked lanes per service, staging, tile order and the size of a
     deferred batch only move work between lanes and launches: each pixel consumes its own RNG stream in the
