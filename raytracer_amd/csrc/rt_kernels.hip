@@ -521,6 +521,12 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   // 2^-24 a (|o|^2 + |c|^2 + r^2) of D while all magnitudes are `tame` (no overflow / underflow);
   // m = 2^-16 = 256 such units, so a negative sign here is a certain miss of the literal code too.
   // Rays or scenes outside the tame range skip the filter (every sphere is a candidate).
+#ifndef RT_RCP_AT_WALK
+#define RT_RCP_AT_WALK 1
+#endif
+  auto ray_reciprocal = [&]() __attribute__((always_inline)) {
+    a_rcp = STRICT ? make_divisor(a_lit).r : __builtin_amdgcn_rcpf(a_lit);
+  };
   auto ray_prelude = [&](auto filter_tag, p1_ray& p1q) __attribute__((always_inline)) {
     constexpr bool FILTER = decltype(filter_tag)::value;
     const float a_fast = dot_fast(dx, dy, dz, dx, dy, dz);
@@ -536,11 +542,12 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     if (STRICT) {
       const float len = sqrt_rn(dot_strict(dx, dy, dz, dx, dy, dz));
       a_lit = len * len;  // length_squared (wgsl:306-309)
-      a_rcp = make_divisor(a_lit).r;
     } else {
       a_lit = a_fast;
-      a_rcp = __builtin_amdgcn_rcpf(a_fast);
     }
+    // MASK shape: the reciprocal is formed where the exact tests run ([W]: once per iteration for primary and bounce rays
+    // together, and only 29 % of the bounce rays get there at all) instead of in both preludes
+    if (!MASK || !RT_RCP_AT_WALK) ray_reciprocal();
   };
 
   // [W] hit_sphere (wgsl:200-231) for the lane's candidates among spheres base .., in ascending sphere order.
@@ -1163,6 +1170,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         // iteration more for that path, in the same ascending sphere order (so with the same result).
         float closest = w_closest;
         int hit = (int)w_hit;
+        if (RT_RCP_AT_WALK) ray_reciprocal();
 #if RT_PROFILE_SECTIONS == 3
         if (hit < 0 && closest == RT_RAY_TMAX) {
           const uint32_t pc = (uint32_t)__popc(cand);
