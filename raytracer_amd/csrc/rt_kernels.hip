@@ -110,6 +110,9 @@ __device__ __forceinline__ float dot_fast(float ax, float ay, float az, float bx
 // the compiler's own expansion without its denormal pre-scaling and class fix-up: v_sqrt_f32 is
 // within 1 ulp, and the two FMA residuals pick the correctly rounded neighbour. Smaller x (0,
 // denormals, negatives) takes the generic path.
+#ifndef RT_RADIUS_RCP_LDS
+#define RT_RADIUS_RCP_LDS 1
+#endif
 #ifndef RT_SQRT_SIGNS
 #define RT_SQRT_SIGNS 1
 #endif
@@ -415,7 +418,16 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     for (uint32_t i = threadIdx.x; i < n_spheres; i += 64u) {
       sph_lds[i] = a.sph_test[i];
       sph_lds[RT_SMALL_MAX + i] = a.sph_shade[i];
-      sph_lds[2u * RT_SMALL_MAX + i] = a.sph_col[i];
+      f32x4 col = a.sph_col[i];
+#if RT_RADIUS_RCP_LDS
+      // strict: a radius that is no power of two (col.w <= 0) is divided by; its refined reciprocal - what make_divisor would
+      // compute per hit, v_rcp_f32 and two FMAs - is formed here once per wave and sphere, as -|.| (NaN: outside div_core's range)
+      if (STRICT && !(col.w > 0.0f)) {
+        const rn_divisor rd = make_divisor(a.sph_shade[i].w);
+        col.w = rd.nice ? -__builtin_fabsf(rd.r) : __builtin_nanf("");
+      }
+#endif
+      sph_lds[2u * RT_SMALL_MAX + i] = col;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -649,7 +661,12 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         // exactly, barring overflow/underflow of a unit-length normal's components
         nx = ex * sc.w; ny = ey * sc.w; nz = ez * sc.w;
       } else {
-        const rn_divisor rd = make_divisor(sg.w);
+        rn_divisor rd;
+        if (SMALL && RT_RADIUS_RCP_LDS) {  // the reciprocal staged in LDS by the wave's prologue (sign of the radius restored)
+          rd.y = sg.w; rd.r = __builtin_copysignf(sc.w, sg.w); rd.nice = sc.w == sc.w;
+        } else {
+          rd = make_divisor(sg.w);
+        }
         div3_rn(ex, ey, ez, rd, nx, ny, nz);
       }
     } else {
