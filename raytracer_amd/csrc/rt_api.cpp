@@ -165,6 +165,7 @@ constexpr uint32_t RT_STAGE_MIN_SPP = 4;   // below that a (tile, frame) unit is
 constexpr size_t RT_STAGE_MAX_BYTES = (size_t)4 << 30;  // largest staging buffer a context allocates
 constexpr uint32_t RT_FRAME_GROUP_MAX = 2u;     // staged launches: frames per unit of work (env RT_FRAME_GROUP overrides; 1 = a unit per frame). C2: 1 / 2 / 4 = 56.4 / 58.1 / 57.8 Gsamples/s, C4 (dear pixels: tails): 5.23 / 5.22 / 4.85 (profiles/r3_sweep_groups.log)
 constexpr uint64_t RT_GROUP_MIN_UNITS = 16u;    // ... while every resident wave keeps at least this many units
+constexpr uint32_t RT_GROUP_MAX_SAMPLES = 32u;  // ... and a lane's share of a unit stays at or below this many samples
 
 // Largest staging buffer a context may allocate: RT_STAGE_MAX_BYTES, and never more than a quarter of the device memory
 // that is free right now (a plain rt_compute loop must not take gigabytes inside an observer call unasked).
@@ -268,7 +269,10 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
       uint32_t g = 1u;
       const bool forced = ctx->frame_group > 0;  // env RT_FRAME_GROUP: that group size (rounded down to a power of two), whatever the launch shape
       const uint32_t g_max = forced ? (uint32_t)ctx->frame_group : RT_FRAME_GROUP_MAX;
-      while (g * 2u <= g_max && g * 2u <= n_frames && (forced || (uint64_t)my_tiles * ((n_frames + 2u * g - 1u) / (2u * g)) >= RT_GROUP_MIN_UNITS * resident)) g *= 2u;
+      // (and only while a unit stays short - at 64 spp a pixel hand-out is 1/64 of the work already and a longer unit only lengthens the launch's tail)
+      while (g * 2u <= g_max && g * 2u <= n_frames &&
+             (forced || ((uint64_t)my_tiles * ((n_frames + 2u * g - 1u) / (2u * g)) >= RT_GROUP_MIN_UNITS * resident && a.spp * g * 2u <= RT_GROUP_MAX_SAMPLES)))
+        g *= 2u;
       a.frame_group = g;
       a.n_groups = (n_frames + g - 1u) / g;
       a.n_units = my_tiles * a.n_groups;
