@@ -216,6 +216,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.n_spheres = ctx->n_spheres;
   a.flags = ctx->flags;
   a.p1_tame = ctx->p1_tame ? 1u : 0u;
+  if (ctx->p1_tame && std::fmaf(a.pos[2], a.pos[2], std::fmaf(a.pos[1], a.pos[1], a.pos[0] * a.pos[0])) <= 0x1p40f) a.p1_tame |= 2u;
   a.sph_p1 = ctx->sph_p1;
   a.sph_test = ctx->sph_test;
   a.sph_shade = ctx->sph_shade;

@@ -33,7 +33,8 @@ struct rt_kargs {
   uint32_t batch_lanes;          // lanes that must be parked before frame ends / pixel hand-outs are serviced
   uint32_t n_spheres;
   uint32_t flags;
-  uint32_t p1_tame;              // 1 when every sphere is inside the magnitude range the phase-1 error bound assumes
+  uint32_t p1_tame;              // bit 0: every sphere is inside the magnitude range the phase-1 error bound assumes; bit 1: bit 0 and
+                                 // the camera position too (|pos|^2 <= 2^40, the FMA form the kernel uses for every other ray origin)
   const float* sph_p1;           // n_spheres rounded up to a multiple of 4, x 4 floats
   const rt_f32x4* sph_test;
   const rt_f32x4* sph_shade;

@@ -511,7 +511,9 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   // dub ~ 2.4e-3 +- a few ulp of x, so every departure with hb >~ 2 - 1.2 degrees above the tangent plane - is dropped;
   // the separate limits needed 11 degrees, and most of the visible ground is seen at less). What keeps its exact test
   // is the last degree above the tangent plane, where the reference's own "shadow acne" lives.
-  auto own_sphere_drop = [&]() __attribute__((always_inline)) -> bool {
+  // `a_d`: |d|^2 - the literal a_lit, or (MASK shape) the FMA form a_fast, which is within 8u of it (each is within a few u
+  // of the exact |d|^2): both a-terms of the inequality move by that factor, the 2^-10 on the right is 16384u.
+  auto own_sphere_drop = [&](float a_d) __attribute__((always_inline)) -> bool {
     const bool has_own = own != 0xffffffffu;  // LIST: a primary ray that takes the general trace (its tile's list overflowed)
     const uint32_t oi = has_own ? own : 0u;
     const f32x4 so = SMALL ? sph_lds[oi] : a.sph_test[oi];  // {c, fl(r r)}
@@ -519,8 +521,8 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     const float x = STRICT ? dot_strict(ex, ey, ez, ex, ey, ez) : dot_fast(ex, ey, ez, ex, ey, ez);
     const float hbo = STRICT ? dot_strict(ex, ey, ez, dx, dy, dz) : dot_fast(ex, ey, ez, dx, dy, dz);
     const float dub = __builtin_fmaf(x, 0x1p-22f, so.w - x);
-    const float lhs = __builtin_fmaf(hbo * hbo, 5.0f * 0x1p-24f, a_lit * dub);
-    const float rhs = (hbo * a_lit) * (2.0f * RT_RAY_TMIN * (1.0f - 0x1p-10f));
+    const float lhs = __builtin_fmaf(hbo * hbo, 5.0f * 0x1p-24f, a_d * dub);
+    const float rhs = (hbo * a_d) * (2.0f * RT_RAY_TMIN * (1.0f - 0x1p-10f));
     return has_own && tame && hbo >= 0x1p-30f && lhs <= rhs;
   };
 
@@ -536,14 +538,25 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
 #ifndef RT_RCP_AT_WALK
 #define RT_RCP_AT_WALK 1
 #endif
-  auto ray_reciprocal = [&]() __attribute__((always_inline)) {
-    a_rcp = STRICT ? make_divisor(a_lit).r : __builtin_amdgcn_rcpf(a_lit);
+  // what the exact tests need of a ray: length_squared(dir) as the shader computes it (wgsl:306-309: sqrt, then square) and
+  // its refined reciprocal
+  auto ray_literal_a = [&]() __attribute__((always_inline)) {
+    if (STRICT) {
+      const float len = sqrt_rn(dot_strict(dx, dy, dz, dx, dy, dz));
+      a_lit = len * len;
+      a_rcp = make_divisor(a_lit).r;
+    } else {
+      a_lit = dot_fast(dx, dy, dz, dx, dy, dz);
+      a_rcp = __builtin_amdgcn_rcpf(a_lit);
+    }
   };
-  auto ray_prelude = [&](auto filter_tag, p1_ray& p1q) __attribute__((always_inline)) {
+  // returns the FMA form of |d|^2
+  auto ray_prelude = [&](auto filter_tag, p1_ray& p1q) __attribute__((always_inline)) -> float {
     constexpr bool FILTER = decltype(filter_tag)::value;
     const float a_fast = dot_fast(dx, dy, dz, dx, dy, dz);
-    const float oo = dot_fast(ox, oy, oz, ox, oy, oz);
-    tame = a.p1_tame != 0u && a_fast >= 0x1p-20f && a_fast <= 0x1p20f && oo <= 0x1p40f;
+    // a primary ray (the preludes without FILTER) starts at the camera: |o|^2 <= 2^40 is bit 1 of p1_tame, decided by the host
+    const float oo = FILTER ? dot_fast(ox, oy, oz, ox, oy, oz) : 0.0f;
+    tame = (FILTER ? (a.p1_tame & 1u) != 0u : (a.p1_tame & 2u) != 0u) && a_fast >= 0x1p-20f && a_fast <= 0x1p20f && oo <= 0x1p40f;
     if (FILTER) {
       const float nod = -dot_fast(ox, oy, oz, dx, dy, dz);
       const float na = -a_fast;
@@ -551,15 +564,11 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       const float a2 = a_fast + a_fast;
       p1q = p1_ray{f32x2{dx, dy}, f32x2{dz, nod}, f32x2{na, nA}, f32x2{a2 * ox, a2 * oy}, f32x2{a2 * oz, 0.0f}};
     }
-    if (STRICT) {
-      const float len = sqrt_rn(dot_strict(dx, dy, dz, dx, dy, dz));
-      a_lit = len * len;  // length_squared (wgsl:306-309)
-    } else {
-      a_lit = a_fast;
-    }
-    // MASK shape: the reciprocal is formed where the exact tests run ([W]: once per iteration for primary and bounce rays
-    // together, and only 29 % of the bounce rays get there at all) instead of in both preludes
-    if (!MASK || !RT_RCP_AT_WALK) ray_reciprocal();
+    // MASK shape: a_lit and its reciprocal (a correctly rounded sqrt, v_rcp_f32 and two FMAs: ~20 instructions) are formed where
+    // the exact tests run ([W]: once per iteration for primary and bounce rays together - and only 29 % of the bounce rays
+    // get there at all) instead of in both preludes; the own-sphere drop works with a_fast.
+    if (!MASK || !RT_RCP_AT_WALK) ray_literal_a();
+    return a_fast;
   };
 
   // [W] hit_sphere (wgsl:200-231) for the lane's candidates among spheres base .., in ascending sphere order.
@@ -777,7 +786,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       ray_prelude(std::integral_constant<bool, true>{}, p1q);
       const unsigned long long any_untame = __ballot(!tame);
       const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
-      const bool own_drop = LIST ? own_sphere_drop() : false;
+      const bool own_drop = LIST ? own_sphere_drop(a_lit) : false;
       if (COUNT) { c_R++; c_T += n_spheres; }
       // CANDIDATE QUEUE (strict launches on scenes of more than RT_SMALL_MAX spheres). A ray of the 1024-sphere scene has
       // 1.4 candidates in all, spread over 32 blocks: walking them block by block ran 18 trips of the exact test per
@@ -1187,7 +1196,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         // iteration more for that path, in the same ascending sphere order (so with the same result).
         float closest = w_closest;
         int hit = (int)w_hit;
-        if (RT_RCP_AT_WALK) ray_reciprocal();
+        if (RT_RCP_AT_WALK) ray_literal_a();
 #if RT_PROFILE_SECTIONS == 3
         if (hit < 0 && closest == RT_RAY_TMAX) {
           const uint32_t pc = (uint32_t)__popc(cand);
@@ -1232,11 +1241,11 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         if (EXEC) { c_R++; c_T += n_spheres; }
         p1_ray p1q;
         probe_bpermute();
-        ray_prelude(std::integral_constant<bool, true>{}, p1q);
+        const float a_fast = ray_prelude(std::integral_constant<bool, true>{}, p1q);
         RT_PROF_END(1);
         RT_PROF_BEGIN(2);
         const uint32_t missbits = phase1_missbits<CULL, P1S>(sph_p1, 0u, n_pad32, p1q);
-        cand = (~missbits | (tame ? 0u : 0xffffffffu)) & valid32 & ~(own_sphere_drop() ? 1u << (n_pad32 - 1u - own) : 0u);
+        cand = (~missbits | (tame ? 0u : 0xffffffffu)) & valid32 & ~(own_sphere_drop(RT_RCP_AT_WALK ? a_fast : a_lit) ? 1u << (n_pad32 - 1u - own) : 0u);
         w_closest = RT_RAY_TMAX; w_hit = 0xffffffffu;  // (own is dead from here on: w_hit shares its register)
         state = ST_TEST;
         if (cand == 0u) shade_miss();
