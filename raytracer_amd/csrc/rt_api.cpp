@@ -321,7 +321,8 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     }
     if (ctx->order_key != key) ctx->have_order = false;
     ctx->order_key = key;
-    measure = !ctx->have_order || ++ctx->order_age >= RT_ORDER_REFRESH;
+    // (counting launches run other kernel shapes - the classic one traces the sky tiles too - and neither measure nor age the order)
+    measure = ctx->counting == 0 && (!ctx->have_order || ++ctx->order_age >= RT_ORDER_REFRESH);
     if (measure) {
       RT_HIP(hipMemsetAsync(ctx->tile_cost, 0, my_tiles * sizeof(uint32_t), ctx->stream));
       a.tile_cost = ctx->tile_cost;
@@ -375,7 +376,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   }
   if (a.staging) RT_HIP(rt_launch_combine_frames(a, ctx->stream));
   if (measure) {
-    RT_HIP(rt_launch_tile_order(ctx->tile_cost, ctx->tile_order, my_tiles, ctx->stream));
+    RT_HIP(rt_launch_tile_order(ctx->tile_cost, a.tile_masks, ctx->tile_order, my_tiles, ctx->stream));
     ctx->have_order = true;
     ctx->order_age = 0;
   }

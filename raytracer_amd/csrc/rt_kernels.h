@@ -63,7 +63,8 @@ hipError_t rt_launch_combine_frames(const rt_kargs& a, hipStream_t stream);
 // masks[j] = spheres a primary ray of this rank's j-th tile can hit, 0 for a sky tile (conservative, double precision);
 // lists (optional, scenes of > 32 spheres): the same as a short list per tile (rt_kargs::tile_lists)
 hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, uint16_t* lists, hipStream_t stream);
-hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t n, hipStream_t stream);
+// order = this rank's tiles, dearest first by `cost`, the sky tiles (masks[j] == 0, or without masks cost[j] == 0) spread evenly between them
+hipError_t rt_launch_tile_order(const uint32_t* cost, const uint32_t* masks, uint32_t* order, uint32_t n, hipStream_t stream);
 // table[i] = {time_bits_host[i] * 87189 + 189273, bits of f32(first_frame + i) / f32(first_frame + i + 1)}, i < n <= 256; the time
 // bits travel as kernel arguments (copied at the call)
 hipError_t rt_launch_frame_table(uint2* table, const uint32_t* time_bits_host, uint32_t first_frame, uint32_t n, hipStream_t stream);

@@ -110,6 +110,9 @@ __device__ __forceinline__ float dot_fast(float ax, float ay, float az, float bx
 // the compiler's own expansion without its denormal pre-scaling and class fix-up: v_sqrt_f32 is
 // within 1 ulp, and the two FMA residuals pick the correctly rounded neighbour. Smaller x (0,
 // denormals, negatives) takes the generic path.
+#ifndef RT_COST_MAX
+#define RT_COST_MAX 1
+#endif
 #ifndef RT_RADIUS_RCP_LDS
 #define RT_RADIUS_RCP_LDS 1
 #endif
@@ -942,7 +945,11 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       }
       if (done) {
         if (ca->rng_out && last_frame) ca->rng_out[pix] = rng;
+#if RT_COST_MAX
+        if (ca->tile_cost) atomicMax(&ca->tile_cost[my_tile], iters);
+#else
         if (ca->tile_cost) atomicAdd(&ca->tile_cost[my_tile], iters);
+#endif
         state = ST_NEED_PIXEL;  // ask for the next pixel
       } else {
         rng = seed_xy ^ ca->frame_table[k].x;
@@ -1511,32 +1518,50 @@ __global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, ui
 
 // Tile order for the next launch: counting sort of this launch's per-tile cost, dearest first.
 // One workgroup; order[] becomes a permutation of [0, n) whatever the costs are.
-__global__ __launch_bounds__(1024) void rt_tile_order_kernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n) {
+__global__ __launch_bounds__(1024) void rt_tile_order_kernel(const uint32_t* __restrict__ cost, const uint32_t* __restrict__ masks, uint32_t* __restrict__ order, uint32_t n) {
+  // bucket 0 = dearest ... 255 = cheapest traced tile, 256 = tiles without cost: sky tiles, which the wave that fetches
+  // them finishes on the spot. The traced tiles are handed out dearest first; the sky tiles are SPREAD EVENLY between them
+  // (round 3): a sky unit is a few microseconds of work behind one atomic on the queue head, and at the end of the queue -
+  // where a plain sort puts all of them - 7168 waves fetching nothing else ran into the rate of atomics on one address
+  // (C3: 7 % of the launch with idle issue slots, profiles/r3_tile_order.md).
   __shared__ uint32_t s_max;
-  __shared__ uint32_t s_hist[256];
-  __shared__ uint32_t s_off[256];
+  __shared__ uint32_t s_hist[257];
+  __shared__ uint32_t s_off[257];
   const uint32_t t = threadIdx.x;
   if (t == 0) s_max = 1u;
-  if (t < 256u) s_hist[t] = 0u;
+  if (t < 257u) s_hist[t] = 0u;
   __syncthreads();
   uint32_t mx = 0;
   for (uint32_t i = t; i < n; i += blockDim.x) mx = cost[i] > mx ? cost[i] : mx;
   atomicMax(&s_max, mx);
   __syncthreads();
   const float scale = 255.0f / (float)s_max;
-  for (uint32_t i = t; i < n; i += blockDim.x) {
-    const uint32_t b = 255u - (uint32_t)((float)cost[i] * scale);  // bucket 0 = dearest
-    atomicAdd(&s_hist[b < 256u ? b : 0u], 1u);
-  }
+  auto bucket = [&](uint32_t i) -> uint32_t {
+    const uint32_t c = cost[i];
+    if (masks ? masks[i] == 0u : c == 0u) return 256u;  // a sky tile by its mask (a launch that traced it anyway gave it a cost)
+    const uint32_t b = 255u - (uint32_t)((float)c * scale);
+    return b < 256u ? b : 0u;
+  };
+  for (uint32_t i = t; i < n; i += blockDim.x) atomicAdd(&s_hist[bucket(i)], 1u);
   __syncthreads();
   if (t == 0) {
     uint32_t acc = 0;
-    for (int b = 0; b < 256; ++b) { s_off[b] = acc; acc += s_hist[b]; }
+    for (int b = 0; b < 257; ++b) { s_off[b] = acc; acc += s_hist[b]; }
   }
   __syncthreads();
+  const unsigned long long n_sky = s_hist[256], n_rest = n - s_hist[256];
   for (uint32_t i = t; i < n; i += blockDim.x) {
-    const uint32_t b = 255u - (uint32_t)((float)cost[i] * scale);
-    order[atomicAdd(&s_off[b < 256u ? b : 0u], 1u)] = i;
+    const unsigned long long r = atomicAdd(&s_off[bucket(i)], 1u);  // rank in the plain sort: traced tiles, then sky tiles
+    unsigned long long pos;
+    if (r < n_rest) {
+      pos = r + (n_sky ? r * n_sky / n_rest : 0ull);                      // floor(r n_sky / n_rest) sky tiles go before traced tile r
+    } else {
+      const unsigned long long sk = r - n_rest;
+      unsigned long long before = n_rest ? ((sk + 1ull) * n_rest + n_sky - 1ull) / n_sky : 0ull;  // traced tiles before sky tile sk
+      if (before > n_rest) before = n_rest;
+      pos = sk + before;
+    }
+    order[pos] = i;
   }
 }
 
@@ -1603,9 +1628,9 @@ hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, uint16_t* li
   return hipGetLastError();
 }
 
-hipError_t rt_launch_tile_order(const uint32_t* cost, uint32_t* order, uint32_t n, hipStream_t stream) {
+hipError_t rt_launch_tile_order(const uint32_t* cost, const uint32_t* masks, uint32_t* order, uint32_t n, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+  hipLaunchKernelGGL(rt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, cost, masks, order, n);
   return hipGetLastError();
 }
 
