@@ -946,7 +946,8 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       if (done) {
         if (ca->rng_out && last_frame) ca->rng_out[pix] = rng;
 #if RT_COST_MAX
-        if (ca->tile_cost) atomicMax(&ca->tile_cost[my_tile], iters);
+        // the tile's dearest pixel: most pixels are not, and a plain load tells (the atomics reach the memory side as write requests)
+        if (ca->tile_cost && __builtin_nontemporal_load(&ca->tile_cost[my_tile]) < iters) atomicMax(&ca->tile_cost[my_tile], iters);
 #else
         if (ca->tile_cost) atomicAdd(&ca->tile_cost[my_tile], iters);
 #endif
