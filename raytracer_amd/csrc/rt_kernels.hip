@@ -259,19 +259,28 @@ __device__ __forceinline__ uint32_t phase1_one(uint32_t missbits, float cx, floa
 template <bool CULL, bool SCALAR>
 __device__ __forceinline__ uint32_t phase1_missbits(const_f32x16_ptr sph_p1, uint32_t base, uint32_t cnt_pad, const p1_ray& q) {
   uint32_t missbits = 0xffffffffu;
-#define RT_P1_FOUR(s)                                                                                                          \
+// HYBRID (an experiment of round 3, off): of the sphere pairs of a scalar-form launch, those whose bit is set in RT_P1_PK_MASK (bit =
+// pair index within an eight-sphere trip) run in the packed form. The window model said a few packed pairs could pay (9 windows
+// nothing shares against 16 that each host a rider); measured on C3, every packed pair costs: one pair in four +1.8 %, two +2.8 %,
+// three +4.1 % (profiles/r3_ab_issue_classes.log) - packed instructions also stop the OTHER waves' instructions from pairing
+// around them (profiles/r3_valu_ceiling.txt, "path mix").
+#ifndef RT_P1_PK_MASK
+#define RT_P1_PK_MASK 0x0
+#endif
+#define RT_P1_PAIR(s, lo, pk)                                                                                                  \
   do {                                                                                                                         \
-    if (SCALAR) {                                                                                                              \
-      missbits = phase1_one<CULL>(missbits, s[0], s[2], s[4], s[6], q);                                                        \
-      missbits = phase1_one<CULL>(missbits, s[1], s[3], s[5], s[7], q);                                                        \
-      missbits = phase1_one<CULL>(missbits, s[8], s[10], s[12], s[14], q);                                                     \
-      missbits = phase1_one<CULL>(missbits, s[9], s[11], s[13], s[15], q);                                                     \
-      break;                                                                                                                   \
+    if (SCALAR && !(pk)) {                                                                                                     \
+      missbits = phase1_one<CULL>(missbits, s[lo], s[lo + 2], s[lo + 4], s[lo + 6], q);                                        \
+      missbits = phase1_one<CULL>(missbits, s[lo + 1], s[lo + 3], s[lo + 5], s[lo + 7], q);                                    \
+    } else {                                                                                                                   \
+      missbits = phase1_pair<CULL>(missbits, __builtin_shufflevector(s, s, lo, lo + 1), __builtin_shufflevector(s, s, lo + 2, lo + 3), \
+                                   __builtin_shufflevector(s, s, lo + 4, lo + 5), __builtin_shufflevector(s, s, lo + 6, lo + 7), q); \
     }                                                                                                                          \
-    missbits = phase1_pair<CULL>(missbits, __builtin_shufflevector(s, s, 0, 1), __builtin_shufflevector(s, s, 2, 3),           \
-                                 __builtin_shufflevector(s, s, 4, 5), __builtin_shufflevector(s, s, 6, 7), q);                 \
-    missbits = phase1_pair<CULL>(missbits, __builtin_shufflevector(s, s, 8, 9), __builtin_shufflevector(s, s, 10, 11),         \
-                                 __builtin_shufflevector(s, s, 12, 13), __builtin_shufflevector(s, s, 14, 15), q);             \
+  } while (0)
+#define RT_P1_FOUR(s, bit0)                                                                                                    \
+  do {                                                                                                                         \
+    RT_P1_PAIR(s, 0, (RT_P1_PK_MASK >> (bit0)) & 1);                                                                           \
+    RT_P1_PAIR(s, 8, (RT_P1_PK_MASK >> ((bit0) + 1)) & 1);                                                                     \
   } while (0)
   const uint32_t n4 = cnt_pad >> 2, b4 = base >> 2;
   uint32_t j = 0;
@@ -281,14 +290,15 @@ __device__ __forceinline__ uint32_t phase1_missbits(const_f32x16_ptr sph_p1, uin
 #if RT_P1_UNROLL
   for (; j + 2u <= n4; j += 2u) {  // eight spheres per trip: both scalar loads in flight before the first is used
     const f32x16 s0 = sph_p1[b4 + j], s1 = sph_p1[b4 + j + 1u];
-    RT_P1_FOUR(s0);
-    RT_P1_FOUR(s1);
+    RT_P1_FOUR(s0, 0);
+    RT_P1_FOUR(s1, 2);
   }
 #endif
   for (; j < n4; ++j) {
     const f32x16 s = sph_p1[b4 + j];  // wave-uniform -> SGPRs
-    RT_P1_FOUR(s);
+    RT_P1_FOUR(s, 0);
   }
+#undef RT_P1_PAIR
 #undef RT_P1_FOUR
   return missbits;
 }
