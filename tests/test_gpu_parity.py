@@ -701,6 +701,34 @@ def test_sky_tiles_follow_the_camera_and_the_scene():
     assert len(set(seen)) == 3 and min(seen) > 0, seen
 
 
+@pytest.mark.parametrize("look,expect", [((0.0, 0.0, -1.0), "mixed"), ((0.0, 1.0, 0.2), "all_sky"), ((0.0, -1.0, -0.05), "no_sky")])
+def test_tile_order_hands_every_tile_out_once(look, expect):
+    """The cost-ordered queue (more tiles than waves: 1024x768 = 12 288 tiles) sorts the traced tiles by their dearest pixel and spreads
+    the sky tiles evenly between them - a permutation of the tiles whatever the split: a view with sky and spheres, one of nothing
+    but sky, one of nothing but the ground. The first launch measures the cost, the later ones use the order; per-frame launches
+    and a batched one, against the oracle."""
+    R = _rt()
+    W, H, frames = 1024, 768, 4
+    spheres, mats = scenes.default_scene(1)
+    cam = scenes.camera_raw(W, H, spp=1, frames=frames + 2, look=look)
+    img = O.OracleImage(W, H, O.ACCUM_F32)
+    cam_after, time_after = O.render(img, spheres, mats, cam, 0, frames)
+    rt = _run_gpu(R, W, H, O.ACCUM_F32, spheres, mats, cam, frames)
+    sky, tiles = rt.sky_tile_stats()
+    assert tiles == 12288 and {"mixed": 0 < sky < tiles, "all_sky": sky == tiles, "no_sky": sky == 0}[expect], (sky, tiles)
+    assert np.array_equal(rt.read_rng_state(), img.rng)
+    assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
+    # two more frames as one batched launch on the same context (the order is in place)
+    cam2 = np.array(cam, copy=True); cam2["current_frame"] = frames
+    rt.set_camera(cam2)
+    rt.render_frames(O.time_bits_table(frames + 2)[frames:])
+    rt.sync()
+    O.render(img, spheres, mats, cam_after, time_after, 2)
+    assert np.array_equal(rt.read_rng_state(), img.rng)
+    assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
+    rt.close()
+
+
 @pytest.mark.parametrize("flags", [0, O.ACCUM_F32, O.ACCUM_F32 | O.COMBINE_SUM], ids=["rgba8", "f32", "f32_sum"])
 def test_deferred_passes_equal_single_launches_and_the_oracle(flags, monkeypatch):
     """rt_compute records a pass; up to RT_DEFER_FRAMES (default 64) recorded passes run as one batched launch when
