@@ -3,6 +3,7 @@
 // fallback anywhere in this library: without a gfx950 device rt_create fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -109,6 +110,13 @@ struct rt_ctx {
   int counting = 0;           // 0 off, 1 the reference algorithm's events (classic shape, every tile traced), 2 the events the production shape executes
   float* sph_p1 = nullptr;
   rt_f32x4 *sph_test = nullptr, *sph_shade = nullptr, *sph_col = nullptr;
+  // uniform grid over the spheres of a big scene (rt_kargs::grid_*); grid_cells == nullptr: none
+  uint32_t* grid_cells = nullptr;
+  uint16_t* grid_refs = nullptr;
+  rt_f32x4* grid_sph = nullptr;
+  float grid_org[3] = {0, 0, 0}, grid_inv[3] = {0, 0, 0}, grid_o2max = 0;
+  uint32_t grid_dim[3] = {0, 0, 0};
+  int use_grid = 1;            // env RT_GRID=0: the general trace always loops over all spheres
   bool p1_tame = false;  // every sphere within the magnitude range of the phase-1 error bound
   uint32_t n_spheres = 0;
   bool have_scene = false, have_camera = false, have_time = false;
@@ -221,6 +229,12 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.sph_test = ctx->sph_test;
   a.sph_shade = ctx->sph_shade;
   a.sph_col = ctx->sph_col;
+  if (ctx->use_grid && ctx->grid_cells) {
+    a.grid_cells = ctx->grid_cells; a.grid_refs = ctx->grid_refs; a.grid_sph = ctx->grid_sph;
+    for (int i = 0; i < 3; ++i) { a.grid_org[i] = ctx->grid_org[i]; a.grid_inv[i] = ctx->grid_inv[i]; a.grid_dim[i] = ctx->grid_dim[i]; }
+    a.grid_ncells = ctx->grid_dim[0] * ctx->grid_dim[1] * ctx->grid_dim[2];
+    a.grid_o2max = ctx->grid_o2max;
+  }
   a.accum = ctx->accum;
   a.rng_out = ctx->rng_capture ? ctx->rng : nullptr;
   a.counters = ctx->counters;
@@ -490,6 +504,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e6 = std::getenv("RT_SKY_TILES")) c->use_sky = std::atoi(e6);
   if (const char* e7 = std::getenv("RT_DEFER_FRAMES")) c->defer_max = std::atoi(e7);
   if (const char* e8 = std::getenv("RT_SPLIT")) c->use_split = std::atoi(e8);
+  if (const char* e9 = std::getenv("RT_GRID")) c->use_grid = std::atoi(e9);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->time_copied, hipEventDisableTiming);
   if (e == hipSuccess) {
     c->stream = c->own_stream;
@@ -530,12 +545,102 @@ void rt_destroy(rt_ctx* c) {
   (void)hipFree(c->sph_test);
   (void)hipFree(c->sph_shade);
   (void)hipFree(c->sph_col);
+  (void)hipFree(c->grid_cells);
+  (void)hipFree(c->grid_refs);
+  (void)hipFree(c->grid_sph);
   (void)hipFree(c->time_dev);
   (void)hipFree(c->quant);
   (void)hipFree(c->staging);
   if (c->time_host) (void)hipHostFree(c->time_host);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+}
+
+// GRID over the spheres of a big scene (rt_kargs::grid_*, DESIGN.md section 4 "grid"). Everything in double; a sphere is listed in
+// every cell its INFLATED ball touches. The inflation covers (a) what the literal arithmetic of hit_sphere can add to a sphere: its
+// discriminant is non-negative only if the ray's line passes within sqrt(r^2 + 54 u S) of the centre, S = |o|^2 + |c|^2 + r^2,
+// u = 2^-24 ("phase-1 filter"); rays with |o|^2 <= o2max use the grid, so S <= S_max = o2max + max(|c|^2 + r^2)
+// and r^2 + 2^-16 S_max (256 u) is ample; (b) the traversal's own rounding (cell coordinates in f32: below 2^-18 of a cell)
+// with 2^-8 of a cell. No grid (the kernel loops over all spheres, as before) when the scene is degenerate, when big spheres would
+// be listed nearly everywhere, or when the lists would outgrow their 16-bit indices' worth.
+static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::vector<float>& p1) {
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, cr2max = 0.0, corner2 = 0.0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const double r = std::fabs((double)sp[i].radius);
+    double cc = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      const double c = sp[i].center[a];
+      lo[a] = std::min(lo[a], c - r); hi[a] = std::max(hi[a], c + r);
+      cc += c * c;
+    }
+    cr2max = std::max(cr2max, cc + r * r);
+  }
+  for (int a = 0; a < 3; ++a) { const double m = std::max(std::fabs(lo[a]), std::fabs(hi[a])); corner2 += m * m; }
+  // ray origins the grid serves: anywhere within twice the scene's reach of the coordinate origin (bounce rays start on spheres)
+  const double o2max = 4.0 * corner2 + 1.0;
+  const double infl2 = 0x1p-16 * (o2max + cr2max);  // added to r^2
+  double ext[3], vol = 1.0;
+  std::vector<double> R(n);
+  double rmax = 0.0;
+  for (uint32_t i = 0; i < n; ++i) { const double r = sp[i].radius; R[i] = std::sqrt(r * r + infl2); rmax = std::max(rmax, R[i]); }
+  for (int a = 0; a < 3; ++a) { lo[a] -= rmax * 0.01 + 1e-3; hi[a] += rmax * 0.01 + 1e-3; }  // (the inflated balls are re-bounded below)
+  for (uint32_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], sp[i].center[a] - R[i]); hi[a] = std::max(hi[a], sp[i].center[a] + R[i]); }
+  for (int a = 0; a < 3; ++a) { ext[a] = hi[a] - lo[a]; if (!(ext[a] > 0.0) || !std::isfinite(ext[a])) return RT_OK; vol *= ext[a]; }
+  // about two cells per sphere, no cell edge below the median inflated diameter's half, at most 64 cells per axis
+  std::vector<double> Rs(R); std::nth_element(Rs.begin(), Rs.begin() + n / 2, Rs.end());
+  const double edge = std::max(std::cbrt(vol / (2.0 * n)), Rs[n / 2]);
+  uint32_t dim[3]; double cell[3];
+  for (int a = 0; a < 3; ++a) {
+    dim[a] = (uint32_t)std::min(64.0, std::max(1.0, std::floor(ext[a] / edge)));
+    cell[a] = ext[a] / dim[a];
+  }
+  const double slack = 0x1p-8 * std::max(cell[0], std::max(cell[1], cell[2]));
+  // pad the box by the slack so that every inflated + slackened ball lies inside it
+  for (int a = 0; a < 3; ++a) { lo[a] -= 2.0 * slack; hi[a] += 2.0 * slack; ext[a] = hi[a] - lo[a]; cell[a] = ext[a] / dim[a]; }
+  const size_t ncells = (size_t)dim[0] * dim[1] * dim[2];
+  std::vector<std::vector<uint16_t>> lists(ncells);
+  size_t total = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const double Ri = R[i] + slack;
+    int c0[3], c1[3];
+    for (int a = 0; a < 3; ++a) {
+      c0[a] = std::max(0, (int)std::floor((sp[i].center[a] - Ri - lo[a]) / cell[a]));
+      c1[a] = std::min((int)dim[a] - 1, (int)std::floor((sp[i].center[a] + Ri - lo[a]) / cell[a]));
+    }
+    for (int z = c0[2]; z <= c1[2]; ++z)
+      for (int y = c0[1]; y <= c1[1]; ++y)
+        for (int x = c0[0]; x <= c1[0]; ++x) {
+          const int ix[3] = {x, y, z};
+          double d2 = 0.0;  // squared distance from the centre to the cell's box
+          for (int a = 0; a < 3; ++a) {
+            const double b0 = lo[a] + ix[a] * cell[a], b1 = b0 + cell[a], c = sp[i].center[a];
+            const double d = c < b0 ? b0 - c : (c > b1 ? c - b1 : 0.0);
+            d2 += d * d;
+          }
+          if (d2 <= Ri * Ri) { lists[((size_t)z * dim[1] + y) * dim[0] + x].push_back((uint16_t)i); ++total; }
+        }
+    if (total > 16u * (size_t)n + 4096u) return RT_OK;  // big spheres listed nearly everywhere: the loop over all spheres is the better trace
+  }
+  std::vector<uint32_t> cells(ncells + 1);
+  std::vector<uint16_t> refs(total + 1);
+  size_t at = 0;
+  for (size_t c = 0; c < ncells; ++c) { cells[c] = (uint32_t)at; for (uint16_t j : lists[c]) refs[at++] = j; }
+  cells[ncells] = (uint32_t)at;
+  std::vector<rt_f32x4> gs(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const float* pp = &p1[(size_t)(i >> 1) * 8u + (i & 1u)];
+    gs[i] = rt_f32x4{pp[0], pp[2], pp[4], pp[6]};
+  }
+  RT_HIP(hipMalloc((void**)&ctx->grid_cells, cells.size() * sizeof(uint32_t)));
+  RT_HIP(hipMalloc((void**)&ctx->grid_refs, refs.size() * sizeof(uint16_t)));
+  RT_HIP(hipMalloc((void**)&ctx->grid_sph, gs.size() * sizeof(rt_f32x4)));
+  RT_HIP(hipMemcpy(ctx->grid_cells, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(ctx->grid_refs, refs.data(), refs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(ctx->grid_sph, gs.data(), gs.size() * sizeof(rt_f32x4), hipMemcpyHostToDevice));
+  for (int a = 0; a < 3; ++a) { ctx->grid_org[a] = (float)lo[a]; ctx->grid_inv[a] = (float)(1.0 / cell[a]); ctx->grid_dim[a] = dim[a]; }
+  ctx->grid_o2max = (float)o2max;
+  return RT_OK;
 }
 
 int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, const rt_material* materials,
@@ -593,6 +698,13 @@ int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, cons
   RT_HIP(hipMemcpy(ctx->sph_test, test.data(), bytes, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(ctx->sph_shade, shade.data(), bytes, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(ctx->sph_col, col.data(), bytes, hipMemcpyHostToDevice));
+  (void)hipFree(ctx->grid_cells);
+  (void)hipFree(ctx->grid_refs);
+  (void)hipFree(ctx->grid_sph);
+  ctx->grid_cells = nullptr; ctx->grid_refs = nullptr; ctx->grid_sph = nullptr;
+  if (tame && n_spheres > 64u && n_spheres <= 0xffffu) {
+    if (int rc = build_grid(ctx, spheres, n_spheres, p1)) return rc;
+  }
   ctx->n_spheres = n_spheres;
   ctx->p1_tame = tame;
   ctx->have_order = false;  // per-tile cost belongs to the old scene

@@ -589,8 +589,17 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   // is below div_core's upper limit, and a numerator under its lower limit 2^-60 gives |quotient| < 2^-38 both
   // exactly and from div_core - far below RT_RAY_TMIN, where only the comparison `root <= tmin` is used.
   // Untamed rays take the compiler's division.
+  // `beyond(root)`: hit_sphere's `closest <= root` (wgsl:216,220). The shader meets the spheres in ascending index, so among equal
+  // roots the lowest index wins; every sphere has ONE root it can be accepted with, whatever `closest` is when it is tested
+  // (root1 if root1 > tmin, else root2 - see RT_ROOT2_LAZY), so the loop's result is (smallest such root, lowest index among
+  // equals) and may be computed in any order with the index compared on ties: the big-scene variants do (ANYORDER), because the
+  // grid trace meets a ray's candidates cell by cell, not by index (and may meet one twice: the second test changes nothing).
+  constexpr bool ANYORDER = !SMALL;
   auto test_sphere = [&](uint32_t i, float& closest, int& hit, unsigned long long any_untame) __attribute__((always_inline)) {
     const rn_divisor a_div = {a_lit, a_rcp, false};
+    auto beyond = [&](float root) __attribute__((always_inline)) -> bool {
+      return ANYORDER ? (closest < root || (closest == root && (int)i >= hit)) : closest <= root;
+    };
     if (EXEC) c_X++;
     {
       const f32x4 s = SMALL ? sph_lds[i] : a.sph_test[i];
@@ -611,17 +620,17 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           // hb and sq finite, sq >= +0) fl(-hb + sq) >= fl(-hb - sq) and the correctly rounded quotients by a_lit keep
           // that order, so `closest <= root1` implies `closest <= root2` - hit_sphere (wgsl:214-222) rejects both.
           const bool behind1 = root <= RT_RAY_TMIN;
-          if (behind1 || closest <= root) {
+          if (behind1 || beyond(root)) {
             ok = false;
             if (behind1 || !tame) {
               root = div_known(-hb + sq, a_div, !tame, any_untame);
-              ok = !(root <= RT_RAY_TMIN || closest <= root);
+              ok = !(root <= RT_RAY_TMIN || beyond(root));
             }
           }
 #else
-          if (root <= RT_RAY_TMIN || closest <= root) {
+          if (root <= RT_RAY_TMIN || beyond(root)) {
             root = div_known(-hb + sq, a_div, !tame, any_untame);
-            if (root <= RT_RAY_TMIN || closest <= root) ok = false;
+            if (root <= RT_RAY_TMIN || beyond(root)) ok = false;
           }
 #endif
           if (ok) { closest = root; hit = (int)i; }
@@ -634,9 +643,12 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           if (COUNT) c_D++;
           const float sq = __builtin_amdgcn_sqrtf(disc);
           const float r0 = (-hb - sq) * a_rcp, r1 = (-hb + sq) * a_rcp;
-          const bool ok0 = r0 > RT_RAY_TMIN && r0 < closest;
+          auto nearer = [&](float r) __attribute__((always_inline)) -> bool {
+            return ANYORDER ? (r < closest || (r == closest && (int)i < hit)) : r < closest;
+          };
+          const bool ok0 = r0 > RT_RAY_TMIN && nearer(r0);
           const float root = ok0 ? r0 : r1;
-          if (root > RT_RAY_TMIN && root < closest) { closest = root; hit = (int)i; }
+          if (root > RT_RAY_TMIN && nearer(root)) { closest = root; hit = (int)i; }
         }
       }
     }
@@ -800,7 +812,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       const unsigned long long any_untame = __ballot(!tame);
       const uint32_t untame_fill = tame ? 0u : 0xffffffffu;
       const bool own_drop = LIST ? own_sphere_drop(a_lit) : false;
-      if (COUNT) { c_R++; c_T += n_spheres; }
+      if (COUNT) c_R++;  // (c_T: below, once it is known whether the lane's filter runs over all spheres or along the grid)
       // CANDIDATE QUEUE (strict launches on scenes of more than RT_SMALL_MAX spheres). A ray of the 1024-sphere scene has
       // 1.4 candidates in all, spread over 32 blocks: walking them block by block ran 18 trips of the exact test per
       // loop iteration with 2.5 of 64 lanes in each (profiles/r2b_section_lanes.log) - a fifth of the kernel's
@@ -823,6 +835,102 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         }
       };
       RT_PROF_END(1);
+      // GRID TRACE (scenes of more than RT_SMALL_MAX spheres for which rt_set_scene built a grid; not the counting launches of
+      // the reference algorithm). A ray of the 1024-sphere scene passes near a handful of spheres, yet the loop below runs the
+      // filter on all of them for every lane. Here each lane walks the cells of a uniform grid along ITS ray (3D-DDA in cell
+      // coordinates) and runs the same filter - the eight FMAs of phase1_one, sphere constants gathered per lane - on the
+      // spheres listed in those cells only; what passes is queued / tested exactly as below. Why nothing is lost: a sphere's
+      // literal discriminant can be non-negative only if the ray's line comes within sqrt(r^2 + 54 u S) of its centre; every
+      // such sphere is listed in each cell its ball of radius sqrt(r^2 + 2^-16 S_max) + slack touches (rt_api.cpp, build_grid),
+      // and the cells the DDA visits cover the ray's points inside the grid's box to within that slack (its rounding moves
+      // a crossing by < 2^-18 of a cell; a corner cell skipped because two crossings tie is touched by the ray only that
+      // close to the corner). Spheres arrive out of index order, possibly twice: see ANYORDER. Lanes the grid cannot serve
+      // (untamed rays, origins beyond grid_o2max) take the loop over all spheres - `blocks` - as before.
+      bool blocks = true;  // this lane still needs the loop over all spheres
+      if (!SMALL && !(COUNT && !SPLIT)) {
+        const rt_kargs_cptr ga = cold_args();
+        if (ga->grid_cells != nullptr) {
+          const bool served = tame && dot_fast(ox, oy, oz, ox, oy, oz) <= ga->grid_o2max;
+          blocks = !served;
+          auto offer = [&](bool pass, uint32_t j) __attribute__((always_inline)) {
+            if (QUEUE) {
+              if (pass) { queue = (queue << 16) | (unsigned long long)j; qn++; }
+              if (__ballot(qn == 4u)) drain();
+            } else {
+              if (pass) test_sphere(j, closest, hit, any_untame);
+            }
+          };
+          // the ray in cell coordinates g + t e; the box is [0, n] per axis
+          const float gx = (ox - ga->grid_org[0]) * ga->grid_inv[0], gy = (oy - ga->grid_org[1]) * ga->grid_inv[1], gz = (oz - ga->grid_org[2]) * ga->grid_inv[2];
+          const float ex = dx * ga->grid_inv[0], ey = dy * ga->grid_inv[1], ez = dz * ga->grid_inv[2];
+          const uint32_t nx = ga->grid_dim[0], ny = ga->grid_dim[1], nz = ga->grid_dim[2];
+          const float inf = __builtin_inff();
+          bool act = served;
+          float t0 = 0.0f, t1 = inf;
+          float rx, ry, rz;  // 1 / e per axis (inf for an axis the ray does not move along)
+          auto slab = [&](float g, float e, float n, float& r) __attribute__((always_inline)) {
+            const bool par = !(__builtin_fabsf(e) >= 0x1p-60f);
+            r = par ? inf : __builtin_amdgcn_rcpf(e);
+            const float ta = (0.0f - g) * r, tb = (n - g) * r;
+            const float tn = par ? -inf : __builtin_fminf(ta, tb), tf = par ? inf : __builtin_fmaxf(ta, tb);
+            if (par && !(g >= 0.0f && g <= n)) act = false;
+            t0 = __builtin_fmaxf(t0, tn); t1 = __builtin_fminf(t1, tf);
+          };
+          slab(gx, ex, (float)nx, rx); slab(gy, ey, (float)ny, ry); slab(gz, ez, (float)nz, rz);
+          act = act && t0 <= t1;
+          // first cell: the one that holds the point at t0 (clamped into the box), and per axis the t of the next crossing
+          auto first = [&](float g, float e, float r, uint32_t n, float& tm, int& ic) __attribute__((always_inline)) {
+            const float pc = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(e, t0, g), 0.0f), (float)n - 0.5f);
+            ic = (int)pc;  // floor: pc >= 0
+            tm = r == inf ? inf : ((float)(ic + (e > 0.0f ? 1 : 0)) - g) * r;
+          };
+          float tmx, tmy, tmz; int ix, iy, iz;
+          first(gx, ex, rx, nx, tmx, ix); first(gy, ey, ry, ny, tmy, iy); first(gz, ez, rz, nz, tmz, iz);
+          const float tdx = __builtin_fabsf(rx), tdy = __builtin_fabsf(ry), tdz = __builtin_fabsf(rz);
+          const int sxs = ex > 0.0f ? 1 : -1, sys = ey > 0.0f ? (int)nx : -(int)nx, szs = ez > 0.0f ? (int)(nx * ny) : -(int)(nx * ny);
+          int cell = (iz * (int)ny + iy) * (int)nx + ix;
+          const float t_end = t1 * (1.0f + 0x1p-16f) + 0x1p-30f;  // walk while the entry of the next cell is not past the box's far side
+          const uint32_t last_cell = ga->grid_ncells - 1u;
+          while (__ballot(act)) {
+            uint32_t lo = 0, hi = 0;
+            if (act) {
+              const uint32_t c = (uint32_t)cell <= last_cell ? (uint32_t)cell : last_cell;  // (a rounding step off the box reads a valid cell: more candidates, never fewer)
+              lo = ga->grid_cells[c]; hi = ga->grid_cells[c + 1u];
+            }
+            for (;;) {
+              const bool more = lo < hi;
+              if (!__ballot(more)) break;
+              bool pass = false;
+              uint32_t j = 0;
+              if (more) {
+                j = ga->grid_refs[lo];
+                lo++;
+                const f32x4 sc = ga->grid_sph[j];
+                float nhb = __builtin_fmaf(sc.z, p1q.dz_nod.x, p1q.dz_nod.y);
+                nhb = __builtin_fmaf(sc.y, p1q.dx_dy.y, nhb);
+                nhb = __builtin_fmaf(sc.x, p1q.dx_dy.x, nhb);
+                float w = __builtin_fmaf(sc.w, p1q.na_nA.x, p1q.na_nA.y);
+                w = __builtin_fmaf(sc.x, p1q.Px_Py.x, w);
+                w = __builtin_fmaf(sc.y, p1q.Px_Py.y, w);
+                w = __builtin_fmaf(sc.z, p1q.Pz_0.x, w);
+                const float test = __builtin_fmaf(nhb, nhb, w);
+                pass = (as_u32(test) >> 31) == 0u && (int)j != hit && !(own_drop && j == own);
+                if (EXEC) c_T++;
+              }
+              offer(pass, j);
+            }
+            if (act) {  // step into the next cell along the ray
+              const bool bx = tmx <= tmy && tmx <= tmz, by = !bx && tmy <= tmz;
+              const float tc = bx ? tmx : (by ? tmy : tmz);
+              cell += bx ? sxs : (by ? sys : szs);
+              tmx += bx ? tdx : 0.0f; tmy += by ? tdy : 0.0f; tmz += (!bx && !by) ? tdz : 0.0f;
+              act = tc <= t_end;
+            }
+          }
+        }
+      }
+      if (COUNT && blocks) c_T += n_spheres;
+      if (__ballot(blocks))
       for (uint32_t base = 0; base < n_spheres; base += 32u) {
         const uint32_t cnt = n_spheres - base < 32u ? n_spheres - base : 32u;
         // ---- phase 1: sign of D + M for spheres base..base+cnt-1 -> bitmask ----
@@ -838,7 +946,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         // ---- phase 2: each lane walks its own candidates in ascending sphere order ----
         // (untamed rays take every sphere; the lowest cnt_pad - cnt bits are padding spheres)
         const uint32_t valid = (cnt_pad == 32u ? 0xffffffffu : (1u << cnt_pad) - 1u) & ~((1u << (cnt_pad - cnt)) - 1u);  // wave-uniform
-        cand = (~missbits | untame_fill) & valid;
+        cand = blocks ? (~missbits | untame_fill) & valid : 0u;
         if (LIST) {  // own-sphere drop (see own_sphere_drop): the sphere the ray starts on, when it is in this block
           const uint32_t rel = own - base;
           if (own_drop && rel < cnt) cand &= ~(1u << (cnt_pad - 1u - rel));
