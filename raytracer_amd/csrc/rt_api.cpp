@@ -560,7 +560,7 @@ void rt_destroy(rt_ctx* c) {
 // every cell its INFLATED ball touches. The inflation covers (a) what the literal arithmetic of hit_sphere can add to a sphere: its
 // discriminant is non-negative only if the ray's line passes within sqrt(r^2 + 54 u S) of the centre, S = |o|^2 + |c|^2 + r^2,
 // u = 2^-24 ("phase-1 filter"); rays with |o|^2 <= o2max use the grid, so S <= S_max = o2max + max(|c|^2 + r^2)
-// and r^2 + 2^-16 S_max (256 u) is ample; (b) the traversal's own rounding (cell coordinates in f32: below 2^-18 of a cell)
+// and r^2 + 2^-18 S_max (64 u S_max) covers it; (b) the traversal's own rounding (cell coordinates in f32: below 2^-18 of a cell)
 // with 2^-8 of a cell. No grid (the kernel loops over all spheres, as before) when the scene is degenerate, when big spheres would
 // be listed nearly everywhere, or when the lists would outgrow their 16-bit indices' worth.
 static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::vector<float>& p1) {
@@ -576,9 +576,9 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
     cr2max = std::max(cr2max, cc + r * r);
   }
   for (int a = 0; a < 3; ++a) { const double m = std::max(std::fabs(lo[a]), std::fabs(hi[a])); corner2 += m * m; }
-  // ray origins the grid serves: anywhere within twice the scene's reach of the coordinate origin (bounce rays start on spheres)
-  const double o2max = 4.0 * corner2 + 1.0;
-  const double infl2 = 0x1p-16 * (o2max + cr2max);  // added to r^2
+  // ray origins the grid serves: within the scene's reach of the coordinate origin (bounce rays start on spheres; 10 % to spare)
+  const double o2max = 1.1 * corner2 + 1.0;
+  const double infl2 = 0x1p-18 * (o2max + cr2max);  // added to r^2: 64 u S_max against the 54 u S the literal discriminant can be off by
   double ext[3], vol = 1.0;
   std::vector<double> R(n);
   double rmax = 0.0;
@@ -589,7 +589,9 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
   for (int a = 0; a < 3; ++a) { ext[a] = hi[a] - lo[a]; if (!(ext[a] > 0.0) || !std::isfinite(ext[a])) return RT_OK; vol *= ext[a]; }
   // about two cells per sphere, no cell edge below the median inflated diameter's half, at most 64 cells per axis
   std::vector<double> Rs(R); std::nth_element(Rs.begin(), Rs.begin() + n / 2, Rs.end());
-  const double edge = std::max(std::cbrt(vol / (2.0 * n)), Rs[n / 2]);
+  double cells_per_sphere = 2.0;  // env RT_GRID_DENSITY (experiments)
+  if (const char* e = std::getenv("RT_GRID_DENSITY")) { const double v = std::atof(e); if (v > 0.01 && v < 100.0) cells_per_sphere = v; }
+  const double edge = std::max(std::cbrt(vol / (cells_per_sphere * n)), Rs[n / 2]);
   uint32_t dim[3]; double cell[3];
   for (int a = 0; a < 3; ++a) {
     dim[a] = (uint32_t)std::min(64.0, std::max(1.0, std::floor(ext[a] / edge)));
@@ -627,10 +629,12 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
   size_t at = 0;
   for (size_t c = 0; c < ncells; ++c) { cells[c] = (uint32_t)at; for (uint16_t j : lists[c]) refs[at++] = j; }
   cells[ncells] = (uint32_t)at;
-  std::vector<rt_f32x4> gs(n);
-  for (uint32_t i = 0; i < n; ++i) {
+  // the filter's constants travel WITH the list entries ({cx, cy, cz, K'} per entry: one gather level less than index -> record)
+  std::vector<rt_f32x4> gs(total + 1);
+  for (size_t e = 0; e < total; ++e) {
+    const uint32_t i = refs[e];
     const float* pp = &p1[(size_t)(i >> 1) * 8u + (i & 1u)];
-    gs[i] = rt_f32x4{pp[0], pp[2], pp[4], pp[6]};
+    gs[e] = rt_f32x4{pp[0], pp[2], pp[4], pp[6]};
   }
   RT_HIP(hipMalloc((void**)&ctx->grid_cells, cells.size() * sizeof(uint32_t)));
   RT_HIP(hipMalloc((void**)&ctx->grid_refs, refs.size() * sizeof(uint16_t)));

@@ -841,7 +841,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
       // coordinates) and runs the same filter - the eight FMAs of phase1_one, sphere constants gathered per lane - on the
       // spheres listed in those cells only; what passes is queued / tested exactly as below. Why nothing is lost: a sphere's
       // literal discriminant can be non-negative only if the ray's line comes within sqrt(r^2 + 54 u S) of its centre; every
-      // such sphere is listed in each cell its ball of radius sqrt(r^2 + 2^-16 S_max) + slack touches (rt_api.cpp, build_grid),
+      // such sphere is listed in each cell its ball of radius sqrt(r^2 + 2^-18 S_max) + slack touches (rt_api.cpp, build_grid),
       // and the cells the DDA visits cover the ray's points inside the grid's box to within that slack (its rounding moves
       // a crossing by < 2^-18 of a cell; a corner cell skipped because two crossings tie is touched by the ray only that
       // close to the corner). Spheres arrive out of index order, possibly twice: see ANYORDER. Lanes the grid cannot serve
@@ -895,7 +895,9 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
             uint32_t lo = 0, hi = 0;
             if (act) {
               const uint32_t c = (uint32_t)cell <= last_cell ? (uint32_t)cell : last_cell;  // (a rounding step off the box reads a valid cell: more candidates, never fewer)
-              lo = ga->grid_cells[c]; hi = ga->grid_cells[c + 1u];
+              unsigned long long lh;  // {start, end}: one 8-byte load (4-byte aligned)
+              __builtin_memcpy(&lh, ga->grid_cells + c, 8);
+              lo = (uint32_t)lh; hi = (uint32_t)(lh >> 32);
             }
             for (;;) {
               const bool more = lo < hi;
@@ -904,8 +906,8 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
               uint32_t j = 0;
               if (more) {
                 j = ga->grid_refs[lo];
+                const f32x4 sc = ga->grid_sph[lo];
                 lo++;
-                const f32x4 sc = ga->grid_sph[j];
                 float nhb = __builtin_fmaf(sc.z, p1q.dz_nod.x, p1q.dz_nod.y);
                 nhb = __builtin_fmaf(sc.y, p1q.dx_dy.y, nhb);
                 nhb = __builtin_fmaf(sc.x, p1q.dx_dy.x, nhb);
