@@ -583,6 +583,9 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
   std::vector<double> R(n);
   double rmax = 0.0;
   for (uint32_t i = 0; i < n; ++i) { const double r = sp[i].radius; R[i] = std::sqrt(r * r + infl2); rmax = std::max(rmax, R[i]); }
+#ifdef RT_BREAK_GRID  // a deliberately unsound grid (spheres listed by 97 % of their radius): tools/fuzz_proofs.py --big must catch it
+  for (uint32_t i = 0; i < n; ++i) R[i] *= 0.97;
+#endif
   for (int a = 0; a < 3; ++a) { lo[a] -= rmax * 0.01 + 1e-3; hi[a] += rmax * 0.01 + 1e-3; }  // (the inflated balls are re-bounded below)
   for (uint32_t i = 0; i < n; ++i)
     for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], sp[i].center[a] - R[i]); hi[a] = std::max(hi[a], sp[i].center[a] + R[i]); }
@@ -622,7 +625,10 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
           }
           if (d2 <= Ri * Ri) { lists[((size_t)z * dim[1] + y) * dim[0] + x].push_back((uint16_t)i); ++total; }
         }
-    if (total > 16u * (size_t)n + 4096u) return RT_OK;  // big spheres listed nearly everywhere: the loop over all spheres is the better trace
+    if (total > 16u * (size_t)n + 4096u) {  // big spheres listed nearly everywhere: the loop over all spheres is the better trace
+      if (std::getenv("RT_GRID_VERBOSE")) std::fprintf(stderr, "rt_set_scene: no grid (%u spheres: more than %zu list entries)\n", n, total);
+      return RT_OK;
+    }
   }
   std::vector<uint32_t> cells(ncells + 1);
   std::vector<uint16_t> refs(total + 1);
@@ -643,6 +649,9 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
   RT_HIP(hipMemcpy(ctx->grid_refs, refs.data(), refs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(ctx->grid_sph, gs.data(), gs.size() * sizeof(rt_f32x4), hipMemcpyHostToDevice));
   for (int a = 0; a < 3; ++a) { ctx->grid_org[a] = (float)lo[a]; ctx->grid_inv[a] = (float)(1.0 / cell[a]); ctx->grid_dim[a] = dim[a]; }
+  if (std::getenv("RT_GRID_VERBOSE"))
+    std::fprintf(stderr, "rt_set_scene: grid %u x %u x %u over %u spheres, %zu list entries (%.2f per cell, %.2f per sphere)\n", dim[0], dim[1], dim[2], n,
+                 total, (double)total / (double)ncells, (double)total / n);
   ctx->grid_o2max = (float)o2max;
   return RT_OK;
 }

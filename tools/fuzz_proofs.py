@@ -3,11 +3,11 @@
 the GPU box when one of the proofs changes; tests/test_gpu_parity.py holds a fixed sample of the same generators).
 
 Every scene is rendered twice in the same arithmetic mode: with everything on (tile masks incl. the occlusion drop,
-candidate lists, own-sphere drop, walk deferral, candidate queue) and with RT_SPLIT=0 RT_SKY_TILES=0 (every ray takes
+candidate lists, own-sphere drop, walk deferral, candidate queue, grid trace) and with RT_SPLIT=0 RT_SKY_TILES=0 RT_GRID=0 (every ray takes
 the general trace against every sphere, no tile masks). The literal arithmetic is the same in both, so ANY differing
 bit of the float image or of the final RNG states means a proof dropped a sphere that mattered.
 
-usage: tools/fuzz_proofs.py [first_seed] [n_seeds] [--fast]
+usage: tools/fuzz_proofs.py [first_seed] [n_seeds] [--fast] [--big]
 """
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
@@ -17,8 +17,13 @@ import raytracer_amd as R
 import scenes
 
 
+FORCE_KIND = None  # --big: only the many-sphere scenes (candidate lists, queue, GRID trace)
+
+
 def scene(rs):
     kind = rs.randint(0, 7)
+    if FORCE_KIND is not None:
+        kind = FORCE_KIND
     scale = float(rs.choice([0.01, 0.3, 1.0, 1.0, 7.0, 500.0]))
     if kind == 0:    # a dense bunch seen from close by or from inside: deep overlap of projections
         n = int(rs.choice([5, 12, 20, 32]))
@@ -69,7 +74,7 @@ def scene(rs):
 
 
 def render(W, H, flags, spheres, mats, cam, frames, env):
-    for k in ("RT_SPLIT", "RT_SKY_TILES"):
+    for k in ("RT_SPLIT", "RT_SKY_TILES", "RT_GRID"):
         os.environ.pop(k, None)
     os.environ.update(env)
     rt = R.Raytracer(W, H, flags)
@@ -89,6 +94,9 @@ def main():
     first = int(args[0]) if args else 0
     n = int(args[1]) if len(args) > 1 else 200
     math = R.RT_MATH_FAST if "--fast" in sys.argv else R.RT_MATH_STRICT
+    global FORCE_KIND
+    if "--big" in sys.argv:
+        FORCE_KIND = 4
     bad = 0
     t0 = time.time()
     by_kind = {}
@@ -100,7 +108,7 @@ def main():
         flags = R.RT_ACCUM_F32 | math | (R.RT_SHADE_CHECKER if seed % 3 == 0 else 0)
         cam = scenes.camera_raw(W, H, spp=spp, frames=2, **camkw)
         on = render(W, H, flags, spheres, mats, cam, 2, {})
-        off = render(W, H, flags, spheres, mats, cam, 2, {"RT_SPLIT": "0", "RT_SKY_TILES": "0"})
+        off = render(W, H, flags, spheres, mats, cam, 2, {"RT_SPLIT": "0", "RT_SKY_TILES": "0", "RT_GRID": "0"})
         same = np.array_equal(on[0], off[0]) and np.array_equal(on[1], off[1])
         k = by_kind.setdefault(kind, [0, 0, 0, 0])
         k[0] += 1; k[1] += 0 if same else 1; k[2] += on[2][0]; k[3] += on[2][1]
