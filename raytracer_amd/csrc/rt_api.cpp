@@ -630,6 +630,13 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
       return RT_OK;
     }
   }
+  // a ray crosses about half of dim0 + dim1 + dim2 cells and filters what each lists: a grid that hands it more than half the
+  // scene that way (few cells, every sphere in most of them) is slower than the wave-uniform loop over all spheres
+  if ((double)total / (double)ncells * 0.5 * (dim[0] + dim[1] + dim[2]) > 0.5 * n) {
+    if (std::getenv("RT_GRID_VERBOSE")) std::fprintf(stderr, "rt_set_scene: no grid (%u spheres: %.1f list entries per cell of %u x %u x %u)\n", n,
+                                                     (double)total / (double)ncells, dim[0], dim[1], dim[2]);
+    return RT_OK;
+  }
   std::vector<uint32_t> cells(ncells + 1);
   std::vector<uint16_t> refs(total + 1);
   size_t at = 0;

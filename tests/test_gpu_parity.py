@@ -1014,3 +1014,65 @@ def test_launch_knobs_change_no_bit(knob, value, monkeypatch):
     assert np.array_equal(rt.read_rng_state(), img.rng)
     assert np.array_equal(rt.read_accum_f32().view(np.uint32), img.accum.view(np.uint32))
     rt.close()
+
+
+def _grid_scene(case):
+    rs = np.random.RandomState(131)
+    mats = scenes.make_materials(rs.random_sample((3, 4)).astype(np.float32))
+    camkw, p2w_zero_row, expect_grid = {}, None, True
+    if case == "camera_inside_the_bunch":          # origins inside the grid's box: the walk starts in the middle of it
+        spheres, mats = scenes.random_bunch(400, 3, 21)
+        camkw = dict(pos=(1.5, -2.0, -30.0), look=(0.3, 0.1, -1.0), fov=0.4)
+    elif case == "camera_beyond_the_grids_reach":  # |o|^2 > grid_o2max: primary rays loop over all spheres, bounce rays walk the grid
+        spheres, mats = scenes.random_bunch(200, 3, 22)
+        camkw = dict(pos=(0.0, 0.0, 400.0), fov=0.03)
+    elif case == "every_sphere_twice":             # equal roots out of index order: the lower index must win (mirror vs diffuse differ)
+        s, mats = scenes.random_bunch(75, 3, 23)
+        spheres = np.concatenate([s, s])           # sphere i and i + 75: different index parity
+    elif case == "flat_sheet":                     # one layer of cells along z
+        centers = [((k % 15) * 0.9 - 6.3, (k // 15) * 0.9 - 4.5, -14.0) for k in range(150)]
+        spheres = scenes.make_spheres(centers, [0.5] * 150, rs.randint(0, 3, size=150))
+    elif case == "rays_parallel_to_an_axis":       # a camera whose rays all have dx == 0: the slab of that axis has no crossings
+        spheres, mats = scenes.random_bunch(120, 3, 24)
+        p2w_zero_row = 0
+    elif case == "mixed_radii_and_signs":          # negative radii are listed by |r|; tiny and big spheres share cells
+        centers = (rs.random_sample((260, 3)) * 2 - 1) * np.array([9.0, 6.0, 6.0]) + np.array([0.0, 0.0, -16.0])
+        radii = rs.choice([0.05, 0.3, -0.4, 0.8, 2.5], size=260)
+        spheres = scenes.make_spheres(centers, radii, rs.randint(0, 3, size=260))
+    elif case == "big_spheres_everywhere_no_grid":  # every sphere touches most cells: rt_set_scene declines the grid
+        centers = (rs.random_sample((90, 3)) * 2 - 1) * 2.0 + np.array([0.0, 0.0, -30.0])
+        spheres = scenes.make_spheres(centers, [6.0] * 90, rs.randint(0, 3, size=90))
+        expect_grid = False
+    else:
+        raise KeyError(case)
+    return spheres, mats, camkw, p2w_zero_row, expect_grid
+
+
+@pytest.mark.parametrize("case", ["camera_inside_the_bunch", "camera_beyond_the_grids_reach", "every_sphere_twice", "flat_sheet",
+                                  "rays_parallel_to_an_axis", "mixed_radii_and_signs", "big_spheres_everywhere_no_grid"])
+def test_grid_trace_of_big_scenes_changes_no_bit(case, monkeypatch, capfd):
+    """Scenes of more than 64 spheres: each lane walks the cells of a uniform grid along its ray and filters only the
+    spheres listed there (rt_api.cpp build_grid, the GRID TRACE of rt_kernels.hip). Spheres arrive out of index order and
+    possibly twice, so hit_sphere's tie rule (wgsl:214-222: the lowest index among equal roots) is applied by index. The
+    strict image is the oracle's with tile lists and without (RT_SPLIT=0: primary rays walk the grid too); in fast
+    arithmetic grid on / off give the same bits (the filter is the same, only the set of spheres it runs on shrinks)."""
+    R = _rt()
+    spheres, mats, camkw, zero_row, expect_grid = _grid_scene(case)
+    W, H, spp, frames = 192, 128, 2, 2
+    cam = scenes.camera_raw(W, H, spp=spp, frames=frames, **camkw)
+    if zero_row is not None:
+        cam["pixel_to_world"][zero_row::4] = 0.0   # row `zero_row` of the column-major matrix: that component of every direction is +-0
+    monkeypatch.setenv("RT_GRID_VERBOSE", "1")
+    capfd.readouterr()
+    for split in ("1", "0"):
+        monkeypatch.setenv("RT_SPLIT", split)
+        _strict_equals_oracle(R, W, H, spp, frames, O.ACCUM_F32, spheres, mats, cam, False)
+    said = capfd.readouterr().err
+    assert ("rt_set_scene: grid " in said) == expect_grid and ("rt_set_scene: no grid" in said) == (not expect_grid), said
+    monkeypatch.delenv("RT_SPLIT")
+    for math in (0x0, 0x8):
+        monkeypatch.setenv("RT_GRID", "1")
+        on = _render_state(R, W, H, O.ACCUM_F32 | math, spheres, mats, cam, frames, True)
+        monkeypatch.setenv("RT_GRID", "0")
+        off = _render_state(R, W, H, O.ACCUM_F32 | math, spheres, mats, cam, frames, True)
+        assert np.array_equal(on[0], off[0]) and np.array_equal(on[1], off[1]), math
