@@ -111,9 +111,8 @@ struct rt_ctx {
   float* sph_p1 = nullptr;
   rt_f32x4 *sph_test = nullptr, *sph_shade = nullptr, *sph_col = nullptr;
   // uniform grid over the spheres of a big scene (rt_kargs::grid_*); grid_cells == nullptr: none
-  uint32_t* grid_cells = nullptr;
-  uint16_t* grid_refs = nullptr;
-  rt_f32x4* grid_sph = nullptr;
+  uint32_t* grid_cells = nullptr;  // the grid's one buffer (build_grid)
+  uint32_t grid_cell0 = 0;
   float grid_org[3] = {0, 0, 0}, grid_inv[3] = {0, 0, 0}, grid_o2max = 0;
   uint32_t grid_dim[3] = {0, 0, 0};
   int use_grid = 1;            // env RT_GRID=0: the general trace always loops over all spheres
@@ -230,7 +229,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.sph_shade = ctx->sph_shade;
   a.sph_col = ctx->sph_col;
   if (ctx->use_grid && ctx->grid_cells) {
-    a.grid_cells = ctx->grid_cells; a.grid_refs = ctx->grid_refs; a.grid_sph = ctx->grid_sph;
+    a.grid_cells = ctx->grid_cells; a.grid_cell0 = ctx->grid_cell0;
     for (int i = 0; i < 3; ++i) { a.grid_org[i] = ctx->grid_org[i]; a.grid_inv[i] = ctx->grid_inv[i]; a.grid_dim[i] = ctx->grid_dim[i]; }
     a.grid_ncells = ctx->grid_dim[0] * ctx->grid_dim[1] * ctx->grid_dim[2];
     a.grid_o2max = ctx->grid_o2max;
@@ -546,8 +545,6 @@ void rt_destroy(rt_ctx* c) {
   (void)hipFree(c->sph_shade);
   (void)hipFree(c->sph_col);
   (void)hipFree(c->grid_cells);
-  (void)hipFree(c->grid_refs);
-  (void)hipFree(c->grid_sph);
   (void)hipFree(c->time_dev);
   (void)hipFree(c->quant);
   (void)hipFree(c->staging);
@@ -637,24 +634,28 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
                                                      (double)total / (double)ncells, dim[0], dim[1], dim[2]);
     return RT_OK;
   }
-  std::vector<uint32_t> cells(ncells + 1);
-  std::vector<uint16_t> refs(total + 1);
-  size_t at = 0;
-  for (size_t c = 0; c < ncells; ++c) { cells[c] = (uint32_t)at; for (uint16_t j : lists[c]) refs[at++] = j; }
-  cells[ncells] = (uint32_t)at;
-  // the filter's constants travel WITH the list entries ({cx, cy, cz, K'} per entry: one gather level less than index -> record)
-  std::vector<rt_f32x4> gs(total + 1);
-  for (size_t e = 0; e < total; ++e) {
-    const uint32_t i = refs[e];
-    const float* pp = &p1[(size_t)(i >> 1) * 8u + (i & 1u)];
-    gs[e] = rt_f32x4{pp[0], pp[2], pp[4], pp[6]};
+  // ONE buffer, addressed by 32-bit byte offsets from its base (a scalar base and a vector offset: no 64-bit address arithmetic
+  // per lane). [0, 32): unused, so that offset 0 can mean "empty cell"; then the list entries, 32 bytes each: the filter's constants
+  // {cx, cy, cz, K'} TRAVEL WITH the entry (one gather level less than index -> record), then the sphere's index with bit 31 set
+  // on the last entry of its cell; then the cell table: per cell the byte offset of its first entry, 0 for an empty cell.
+  const size_t cell0 = 32u + total * 32u, bytes = cell0 + ncells * 4u;
+  if (bytes > 0x7fffffffu) return RT_OK;
+  std::vector<uint32_t> buf(bytes / 4u, 0u);
+  size_t at = 32u;
+  for (size_t c = 0; c < ncells; ++c) {
+    if (lists[c].empty()) continue;
+    buf[(cell0 >> 2) + c] = (uint32_t)at;
+    for (size_t e = 0; e < lists[c].size(); ++e, at += 32u) {
+      const uint32_t i = lists[c][e];
+      const float* pp = &p1[(size_t)(i >> 1) * 8u + (i & 1u)];
+      const float rec[4] = {pp[0], pp[2], pp[4], pp[6]};
+      std::memcpy(&buf[at >> 2], rec, 16);
+      buf[(at >> 2) + 4u] = i | (e + 1 == lists[c].size() ? 0x80000000u : 0u);
+    }
   }
-  RT_HIP(hipMalloc((void**)&ctx->grid_cells, cells.size() * sizeof(uint32_t)));
-  RT_HIP(hipMalloc((void**)&ctx->grid_refs, refs.size() * sizeof(uint16_t)));
-  RT_HIP(hipMalloc((void**)&ctx->grid_sph, gs.size() * sizeof(rt_f32x4)));
-  RT_HIP(hipMemcpy(ctx->grid_cells, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(ctx->grid_refs, refs.data(), refs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(ctx->grid_sph, gs.data(), gs.size() * sizeof(rt_f32x4), hipMemcpyHostToDevice));
+  RT_HIP(hipMalloc((void**)&ctx->grid_cells, bytes));
+  RT_HIP(hipMemcpy(ctx->grid_cells, buf.data(), bytes, hipMemcpyHostToDevice));
+  ctx->grid_cell0 = (uint32_t)cell0;
   for (int a = 0; a < 3; ++a) { ctx->grid_org[a] = (float)lo[a]; ctx->grid_inv[a] = (float)(1.0 / cell[a]); ctx->grid_dim[a] = dim[a]; }
   if (std::getenv("RT_GRID_VERBOSE"))
     std::fprintf(stderr, "rt_set_scene: grid %u x %u x %u over %u spheres, %zu list entries (%.2f per cell, %.2f per sphere)\n", dim[0], dim[1], dim[2], n,
@@ -719,9 +720,7 @@ int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, cons
   RT_HIP(hipMemcpy(ctx->sph_shade, shade.data(), bytes, hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(ctx->sph_col, col.data(), bytes, hipMemcpyHostToDevice));
   (void)hipFree(ctx->grid_cells);
-  (void)hipFree(ctx->grid_refs);
-  (void)hipFree(ctx->grid_sph);
-  ctx->grid_cells = nullptr; ctx->grid_refs = nullptr; ctx->grid_sph = nullptr;
+  ctx->grid_cells = nullptr;
   if (tame && n_spheres > 64u && n_spheres <= 0xffffu) {
     if (int rc = build_grid(ctx, spheres, n_spheres, p1)) return rc;
   }

@@ -51,13 +51,14 @@ struct rt_kargs {
   const uint16_t* tile_lists;    // optional, scenes of > 32 spheres, 16 x u16 per tile of this rank: [0] = number of spheres a
                                  // primary ray of the tile can hit (<= 15; 0xffff = more, or rays not provably tame), [1..] their
                                  // indices in ascending order
-  // GRID (scenes of more than 64 spheres, optional: rt_set_scene builds it when it pays): a uniform grid over the spheres; cell c lists
-  // the spheres whose INFLATED ball (radius^2 + 2^-18 S_max, plus the traversal's slack) touches it, grid_refs[grid_cells[c] ..
-  // grid_cells[c + 1]). The general trace of a ray whose origin satisfies |o|^2 <= grid_o2max walks the cells along the ray and
-  // runs the phase-1 filter on the listed spheres only (rt_kernels.hip, "grid"); other rays take the loop over all spheres.
-  const uint32_t* grid_cells;      // null: no grid
-  const uint16_t* grid_refs;
-  const rt_f32x4* grid_sph;        // {cx, cy, cz, K'} per LIST ENTRY (the constants of sph_p1 of sphere grid_refs[e])
+  // GRID (scenes of more than 64 spheres, optional: rt_set_scene builds it when it pays): a uniform grid over the spheres; a cell lists
+  // the spheres whose INFLATED ball (radius^2 + 2^-18 S_max, plus the traversal's slack) touches it. One buffer, addressed by byte
+  // offsets from its base: the cell table at grid_cell0 (per cell the offset of its first list entry, 0 = empty cell), entries of
+  // 32 bytes {cx, cy, cz, K' (the filter's constants of sph_p1), sphere index | last-of-its-cell << 31, -, -, -} (rt_api.cpp, build_grid).
+  // The general trace of a ray whose origin satisfies |o|^2 <= grid_o2max walks the cells along the ray and runs the phase-1 filter
+  // on the listed spheres only (rt_kernels.hip, "grid"); other rays take the loop over all spheres.
+  const uint32_t* grid_cells;      // the buffer; null: no grid
+  uint32_t grid_cell0;
   float grid_org[3], grid_inv[3];  // cell coordinates of a point p: (p - org) * inv
   uint32_t grid_dim[3], grid_ncells;
   float grid_o2max;

@@ -852,14 +852,6 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         if (ga->grid_cells != nullptr) {
           const bool served = tame && dot_fast(ox, oy, oz, ox, oy, oz) <= ga->grid_o2max;
           blocks = !served;
-          auto offer = [&](bool pass, uint32_t j) __attribute__((always_inline)) {
-            if (QUEUE) {
-              if (pass) { queue = (queue << 16) | (unsigned long long)j; qn++; }
-              if (__ballot(qn == 4u)) drain();
-            } else {
-              if (pass) test_sphere(j, closest, hit, any_untame);
-            }
-          };
           // the ray in cell coordinates g + t e; the box is [0, n] per axis
           const float gx = (ox - ga->grid_org[0]) * ga->grid_inv[0], gy = (oy - ga->grid_org[1]) * ga->grid_inv[1], gz = (oz - ga->grid_org[2]) * ga->grid_inv[2];
           const float ex = dx * ga->grid_inv[0], ey = dy * ga->grid_inv[1], ez = dz * ga->grid_inv[2];
@@ -886,48 +878,62 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           };
           float tmx, tmy, tmz; int ix, iy, iz;
           first(gx, ex, rx, nx, tmx, ix); first(gy, ey, ry, ny, tmy, iy); first(gz, ez, rz, nz, tmz, iz);
-          const float tdx = __builtin_fabsf(rx), tdy = __builtin_fabsf(ry), tdz = __builtin_fabsf(rz);
-          const int sxs = ex > 0.0f ? 1 : -1, sys = ey > 0.0f ? (int)nx : -(int)nx, szs = ez > 0.0f ? (int)(nx * ny) : -(int)(nx * ny);
-          int cell = (iz * (int)ny + iy) * (int)nx + ix;
+          // ONE FLAT LOOP per wave instead of "for each cell: for each entry" (where every cell cost the wave as many trips as its
+          // fullest list among 64 rays in 64 different cells): per trip a lane EITHER takes the next entry of its cell's list (`cur`,
+          // a byte offset into the grid's buffer; 0: none) OR steps to the next cell along its ray (`coff`, the byte offset of the
+          // cell's table entry; DONE past the box), whose list offset was fetched one step ahead (`nxt`). Offsets are 32-bit
+          // against a scalar base: no per-lane 64-bit address arithmetic.
+          const char* const gbase = reinterpret_cast<const char*>(ga->grid_cells);
+          const char* const cbase = gbase + ga->grid_cell0;  // the cell table; `coff` is relative to it
+          const uint32_t coff_last = 4u * (nx * ny * nz - 1u), DONE = 0xffffffffu;
+          const int sxs = ex > 0.0f ? 4 : -4, sys = ey > 0.0f ? (int)(4u * nx) : -(int)(4u * nx), szs = ez > 0.0f ? (int)(4u * nx * ny) : -(int)(4u * nx * ny);
           const float t_end = t1 * (1.0f + 0x1p-16f) + 0x1p-30f;  // walk while the entry of the next cell is not past the box's far side
-          const uint32_t last_cell = ga->grid_ncells - 1u;
-          while (__ballot(act)) {
-            uint32_t lo = 0, hi = 0;
-            if (act) {
-              const uint32_t c = (uint32_t)cell <= last_cell ? (uint32_t)cell : last_cell;  // (a rounding step off the box reads a valid cell: more candidates, never fewer)
-              unsigned long long lh;  // {start, end}: one 8-byte load (4-byte aligned)
-              __builtin_memcpy(&lh, ga->grid_cells + c, 8);
-              lo = (uint32_t)lh; hi = (uint32_t)(lh >> 32);
+          auto cell_list = [&](uint32_t co) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t c = co <= coff_last ? co : coff_last;  // (a rounding step off the box - below 0 wraps - reads a valid cell: more candidates, never fewer)
+            return *reinterpret_cast<const uint32_t*>(cbase + c);
+          };
+          uint32_t coff = act ? 4u * (uint32_t)((iz * (int)ny + iy) * (int)nx + ix) : DONE;
+          uint32_t cur = 0u, nxt = 0u;
+          if (act) nxt = cell_list(coff);
+          // a candidate the lane queued last is not queued again (a sphere is listed in every cell it touches, and a ray that comes
+          // near it usually crosses several of them): testing a sphere twice changes nothing, so neither does leaving the repeat out
+          uint32_t lastj = own_drop ? own : 0xffffffffu;
+          const uint32_t skipj = lastj;
+          for (;;) {
+            if (cur == 0u && coff != DONE) {  // into the cell `coff`, and the crossing that leaves it
+              cur = nxt;
+              const float tc = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz);
+              const bool bx = tmx == tc, by = !bx && tmy == tc;
+              const int inc = bx ? sxs : (by ? sys : szs);
+              tmx += bx ? __builtin_fabsf(rx) : 0.0f; tmy += by ? __builtin_fabsf(ry) : 0.0f; tmz += (!bx && !by) ? __builtin_fabsf(rz) : 0.0f;
+              coff = tc <= t_end ? coff + (uint32_t)inc : DONE;
+              if (coff != DONE) nxt = cell_list(coff);
             }
-            for (;;) {
-              const bool more = lo < hi;
-              if (!__ballot(more)) break;
-              bool pass = false;
-              uint32_t j = 0;
-              if (more) {
-                j = ga->grid_refs[lo];
-                const f32x4 sc = ga->grid_sph[lo];
-                lo++;
-                float nhb = __builtin_fmaf(sc.z, p1q.dz_nod.x, p1q.dz_nod.y);
-                nhb = __builtin_fmaf(sc.y, p1q.dx_dy.y, nhb);
-                nhb = __builtin_fmaf(sc.x, p1q.dx_dy.x, nhb);
-                float w = __builtin_fmaf(sc.w, p1q.na_nA.x, p1q.na_nA.y);
-                w = __builtin_fmaf(sc.x, p1q.Px_Py.x, w);
-                w = __builtin_fmaf(sc.y, p1q.Px_Py.y, w);
-                w = __builtin_fmaf(sc.z, p1q.Pz_0.x, w);
-                const float test = __builtin_fmaf(nhb, nhb, w);
-                pass = (as_u32(test) >> 31) == 0u && (int)j != hit && !(own_drop && j == own);
-                if (EXEC) c_T++;
-              }
-              offer(pass, j);
+            bool pass = false;
+            uint32_t j = 0;
+            if (cur != 0u) {
+              const f32x4 sc = *reinterpret_cast<const f32x4*>(gbase + cur);
+              const uint32_t jw = *reinterpret_cast<const uint32_t*>(gbase + cur + 16u);
+              cur = (int)jw < 0 ? 0u : cur + 32u;
+              j = jw & 0x7fffffffu;
+              float nhb = __builtin_fmaf(sc.z, p1q.dz_nod.x, p1q.dz_nod.y);
+              nhb = __builtin_fmaf(sc.y, p1q.dx_dy.y, nhb);
+              nhb = __builtin_fmaf(sc.x, p1q.dx_dy.x, nhb);
+              float w = __builtin_fmaf(sc.w, p1q.na_nA.x, p1q.na_nA.y);
+              w = __builtin_fmaf(sc.x, p1q.Px_Py.x, w);
+              w = __builtin_fmaf(sc.y, p1q.Px_Py.y, w);
+              w = __builtin_fmaf(sc.z, p1q.Pz_0.x, w);
+              const float test = __builtin_fmaf(nhb, nhb, w);
+              pass = (int)as_u32(test) >= 0 && j != lastj && j != skipj;
+              if (EXEC) c_T++;
             }
-            if (act) {  // step into the next cell along the ray
-              const bool bx = tmx <= tmy && tmx <= tmz, by = !bx && tmy <= tmz;
-              const float tc = bx ? tmx : (by ? tmy : tmz);
-              cell += bx ? sxs : (by ? sys : szs);
-              tmx += bx ? tdx : 0.0f; tmy += by ? tdy : 0.0f; tmz += (!bx && !by) ? tdz : 0.0f;
-              act = tc <= t_end;
+            if (QUEUE) {
+              if (pass) { queue = (queue << 16) | (unsigned long long)j; qn++; lastj = j; }
+              if (__ballot(qn == 4u)) drain();
+            } else {
+              if (pass) { lastj = j; test_sphere(j, closest, hit, any_untame); }
             }
+            if (!__ballot(cur != 0u || coff != DONE)) break;
           }
         }
       }
