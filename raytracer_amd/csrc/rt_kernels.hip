@@ -927,12 +927,10 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
               pass = (int)as_u32(test) >= 0 && j != lastj && j != skipj;
               if (EXEC) c_T++;
             }
-            if (QUEUE) {
-              if (pass) { queue = (queue << 16) | (unsigned long long)j; qn++; lastj = j; }
-              if (__ballot(qn == 4u)) drain();
-            } else {
-              if (pass) { lastj = j; test_sphere(j, closest, hit, any_untame); }
-            }
+            // (both arithmetic modes queue here: an exact test inside this loop would run for the one or two lanes that have a
+            // candidate in most trips of the wave)
+            if (pass) { queue = (queue << 16) | (unsigned long long)j; qn++; lastj = j; }
+            if (__ballot(qn == 4u)) drain();
             if (!__ballot(cur != 0u || coff != DONE)) break;
           }
         }
@@ -984,7 +982,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         }
         RT_PROF_END(3);
       }
-      if (QUEUE && use_queue) {
+      if ((QUEUE && use_queue) || !SMALL) {  // (the grid trace queues in fast arithmetic too)
         RT_PROF_BEGIN(3);
         drain();
         RT_PROF_END(3);
