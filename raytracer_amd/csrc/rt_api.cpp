@@ -115,7 +115,7 @@ struct rt_ctx {
   uint32_t grid_cell0 = 0;
   float grid_org[3] = {0, 0, 0}, grid_inv[3] = {0, 0, 0}, grid_o2max = 0;
   uint32_t grid_dim[3] = {0, 0, 0};
-  int use_grid = 1;            // env RT_GRID=0: the general trace always loops over all spheres
+  int use_grid = 1;            // env RT_GRID=0: the general trace always loops over all spheres; 2: a grid whenever one can be built
   bool p1_tame = false;  // every sphere within the magnitude range of the phase-1 error bound
   uint32_t n_spheres = 0;
   bool have_scene = false, have_camera = false, have_time = false;
@@ -627,11 +627,15 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
       return RT_OK;
     }
   }
-  // a ray crosses about half of dim0 + dim1 + dim2 cells and filters what each lists: a grid that hands it more than half the
-  // scene that way (few cells, every sphere in most of them) is slower than the wave-uniform loop over all spheres
-  if ((double)total / (double)ncells * 0.5 * (dim[0] + dim[1] + dim[2]) > 0.5 * n) {
-    if (std::getenv("RT_GRID_VERBOSE")) std::fprintf(stderr, "rt_set_scene: no grid (%u spheres: %.1f list entries per cell of %u x %u x %u)\n", n,
-                                                     (double)total / (double)ncells, dim[0], dim[1], dim[2]);
+  // WHEN THE GRID PAYS (tools/grid_crossover.py, profiles/r3_grid_crossover.md: bunches of 65 ... 16384 unit spheres, both traces timed):
+  // a wave walks until its longest ray is through - about 1.5 x the mean ray's half of dim0 + dim1 + dim2 cells, one trip of ~60
+  // instructions per cell and per listed sphere - while the loop over all spheres costs it ~12 instructions per sphere with the exact
+  // tests: the grid is used when trips < n / 5 (the measured crossover of the bunches lies between 200 and 300 spheres; a grid
+  // of few cells that list every sphere never gets there). RT_GRID=2 builds it regardless (tests of the walk on small scenes).
+  const double trips = 0.75 * (dim[0] + dim[1] + dim[2]) * (1.0 + (double)total / (double)ncells);
+  if (ctx->use_grid != 2 && trips > 0.2 * n) {
+    if (std::getenv("RT_GRID_VERBOSE")) std::fprintf(stderr, "rt_set_scene: no grid (%u spheres: about %.0f trips per wave through %u x %u x %u cells, %.1f entries per cell)\n", n,
+                                                     trips, dim[0], dim[1], dim[2], (double)total / (double)ncells);
     return RT_OK;
   }
   // ONE buffer, addressed by 32-bit byte offsets from its base (a scalar base and a vector offset: no 64-bit address arithmetic

@@ -1063,6 +1063,8 @@ def test_grid_trace_of_big_scenes_changes_no_bit(case, monkeypatch, capfd):
     if zero_row is not None:
         cam["pixel_to_world"][zero_row::4] = 0.0   # row `zero_row` of the column-major matrix: that component of every direction is +-0
     monkeypatch.setenv("RT_GRID_VERBOSE", "1")
+    grid_on = "2" if expect_grid else "1"  # 2: build the grid although the scene is below the size from which it pays (rt_api.cpp, build_grid)
+    monkeypatch.setenv("RT_GRID", grid_on)
     capfd.readouterr()
     for split in ("1", "0"):
         monkeypatch.setenv("RT_SPLIT", split)
@@ -1071,7 +1073,7 @@ def test_grid_trace_of_big_scenes_changes_no_bit(case, monkeypatch, capfd):
     assert ("rt_set_scene: grid " in said) == expect_grid and ("rt_set_scene: no grid" in said) == (not expect_grid), said
     monkeypatch.delenv("RT_SPLIT")
     for math in (0x0, 0x8):
-        monkeypatch.setenv("RT_GRID", "1")
+        monkeypatch.setenv("RT_GRID", grid_on)
         on = _render_state(R, W, H, O.ACCUM_F32 | math, spheres, mats, cam, frames, True)
         monkeypatch.setenv("RT_GRID", "0")
         off = _render_state(R, W, H, O.ACCUM_F32 | math, spheres, mats, cam, frames, True)

@@ -107,7 +107,7 @@ def main():
         spp = int(rs.choice([1, 2, 4]))
         flags = R.RT_ACCUM_F32 | math | (R.RT_SHADE_CHECKER if seed % 3 == 0 else 0)
         cam = scenes.camera_raw(W, H, spp=spp, frames=2, **camkw)
-        on = render(W, H, flags, spheres, mats, cam, 2, {})
+        on = render(W, H, flags, spheres, mats, cam, 2, {"RT_GRID": "2"})  # 2: the grid trace also below the scene size from which it pays
         off = render(W, H, flags, spheres, mats, cam, 2, {"RT_SPLIT": "0", "RT_SKY_TILES": "0", "RT_GRID": "0"})
         same = np.array_equal(on[0], off[0]) and np.array_equal(on[1], off[1])
         k = by_kind.setdefault(kind, [0, 0, 0, 0])
