@@ -899,7 +899,9 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           // near it usually crosses several of them): testing a sphere twice changes nothing, so neither does leaving the repeat out
           uint32_t lastj = own_drop ? own : 0xffffffffu;
           const uint32_t skipj = lastj;
+          RT_PROF_BEGIN(2);
           for (;;) {
+            if (cur != 0u || coff != DONE) { RT_PROF_LANES(2); }  // (profile builds: lanes still walking in this trip)
             if (cur == 0u && coff != DONE) {  // into the cell `coff`, and the crossing that leaves it
               cur = nxt;
               const float tc = __builtin_fminf(__builtin_fminf(tmx, tmy), tmz);
@@ -912,6 +914,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
             bool pass = false;
             uint32_t j = 0;
             if (cur != 0u) {
+              RT_PROF_LANES(4);  // (profile builds: lanes that take a list entry in this trip)
               const f32x4 sc = *reinterpret_cast<const f32x4*>(gbase + cur);
               const uint32_t jw = *reinterpret_cast<const uint32_t*>(gbase + cur + 16u);
               cur = (int)jw < 0 ? 0u : cur + 32u;
@@ -931,8 +934,12 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
             // candidate in most trips of the wave)
             if (pass) { queue = (queue << 16) | (unsigned long long)j; qn++; lastj = j; }
             if (__ballot(qn == 4u)) drain();
+            // (Measured and left out, profiles/r3_grid_suspend.log: stopping the loop when fewer than 12 / 20 / 28 / 36 / 44 lanes are
+            // still walking - they park their walk in LDS and take it up in the next general trace, beside the fresh rays - is
+            // bit-identical and 1.5 / 2 / 4 / 8 / 13 % SLOWER: lane-trips are conserved, and the lanes set free wait for the batch.)
             if (!__ballot(cur != 0u || coff != DONE)) break;
           }
+          RT_PROF_END(2);
         }
       }
       if (COUNT && blocks) c_T += n_spheres;
@@ -1444,7 +1451,9 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
     const unsigned long long life = __builtin_amdgcn_s_memtime() - prof_start;
     const unsigned long long rlife = __builtin_amdgcn_s_memrealtime() - prof_rstart;  // 100 MHz
 #if RT_PROFILE_SECTIONS >= 2
-    const unsigned long long pv[8] = {prof_lds[0], prof_lds[1], prof_lds[2], prof_lds[3], prof_lds[4], life, prof_iters, rlife};
+    // (lanes in the low 38 bits, executions / 16 above them: the sum over all waves of a 20-pass launch stays inside its 26 bits)
+    auto repack = [](unsigned long long v) { return (v & ((1ull << 38) - 1ull)) | ((v >> 42) << 38); };
+    const unsigned long long pv[8] = {repack(prof_lds[0]), repack(prof_lds[1]), repack(prof_lds[2]), repack(prof_lds[3]), repack(prof_lds[4]), life, prof_iters, rlife};
     prof_p2_lanes = prof_lds[5] & ((1ull << 38) - 1ull); prof_p2_waves = prof_lds[5] >> 38;
 #else
     const unsigned long long pv[8] = {prof_acc0, prof_acc1, prof_acc2, prof_acc3, prof_acc4, life, prof_iters, rlife};

@@ -49,10 +49,13 @@ def run(name, W, H, spp, scene, shade, math):
     if os.environ.get("SECTION_LANES"):  # library built with -DRT_PROFILE_SECTIONS=2: lane occupancy per section
         occ = rt.occupancy()
         print(f"{name} {'fast' if math else 'strict'}: {iters} wave-iterations")
-        for label, key in (("[G0] new ray", "T"), ("[P1] prelude + phase 1", "D"), ("rejection round", "H"), ("scatter", "R"), ("normalize", "M")):
-            lanes, execs = c[key] & ((1 << 38) - 1), c[key] >> 38
-            print(f"   {label:24s} {execs / iters:5.2f} executions per iteration, {lanes / max(execs, 1):5.1f} of 64 lanes")
-        print(f"   {'candidate walk trip':24s} {occ['slots_reject'] / iters:5.2f} executions per iteration, {occ['slots_trace'] / max(occ['slots_reject'], 1):5.1f} of 64 lanes")
+        labels = ("[G0] new ray", "[P1] prelude + phase 1", "rejection round", "scatter", "normalize")
+        if len(sp) > 64:  # LIST shape: the slots of the rounds and of normalize count the grid walk instead
+            labels = ("[G0] new ray", "[C] general trace", "grid trip: lanes still walking", "exact test of a tile-list entry", "grid trip: lanes taking a list entry")
+        for label, key in zip(labels, ("T", "D", "H", "R", "M")):
+            lanes, execs = c[key] & ((1 << 38) - 1), (c[key] >> 38) * 16  # (the kernel reports executions / 16 per wave)
+            print(f"   {label:36s} {execs / iters:6.2f} executions per iteration, {lanes / max(execs, 1):5.1f} of 64 lanes")
+        print(f"   {'candidate walk trip':36s} {occ['slots_reject'] / iters:6.2f} executions per iteration, {occ['slots_trace'] / max(occ['slots_reject'], 1):5.1f} of 64 lanes")
         print("   iterations by lanes holding a path: none %.1f %%, 1-16 %.1f %%, 17-48 %.1f %%, 49-64 %.1f %%" % tuple(100.0 * c[k] / iters for k in ("Sd", "N", "P", "rand_calls")))
         rt.close()
         return
