@@ -90,13 +90,15 @@ def test_static_entry_point_rejects_what_it_cannot_hold():
 def test_static_entry_point_allocates_no_device_memory_big_scene_and_partition():
     """check the property the entry point exists for. After one warm-up call (the first launch of a kernel loads
     its code object), free device memory must not move over further static calls - on the MASK path (20 spheres), on the
-    classic path of a scene above 64 spheres (all-ones masks from the scratch, no lists) and under a tile partition."""
+    classic path of a scene above 64 spheres (all-ones masks from the scratch, no lists; at 400 spheres its general trace walks
+    the grid rt_set_scene built) and under a tile partition."""
     import torch
 
     import raytracer_amd as R
 
     cases = [dict(W=272, H=208, flags=R.RT_ACCUM_F32 | R.RT_SHADE_CHECKER, spp=2, frames=64, scene=scenes.random_bunch(20, 3, 3), partition=None),
              dict(W=160, H=128, flags=R.RT_ACCUM_F32, spp=2, frames=64, scene=scenes.random_bunch(200, 4, 16), partition=None),
+             dict(W=160, H=128, flags=R.RT_ACCUM_F32, spp=2, frames=64, scene=scenes.random_bunch(400, 4, 17), partition=None),  # big enough for the grid trace
              dict(W=272, H=208, flags=R.RT_ACCUM_RGBA8, spp=2, frames=64, scene=scenes.default_scene(1), partition=(1, 3))]
     for c in cases:
         sp, mt = c["scene"]
