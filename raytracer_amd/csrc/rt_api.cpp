@@ -559,7 +559,8 @@ void rt_destroy(rt_ctx* c) {
 // u = 2^-24 ("phase-1 filter"); rays with |o|^2 <= o2max use the grid, so S <= S_max = o2max + max(|c|^2 + r^2)
 // and r^2 + 2^-18 S_max (64 u S_max) covers it; (b) the traversal's own rounding (cell coordinates in f32: below 2^-18 of a cell)
 // with 2^-8 of a cell. No grid (the kernel loops over all spheres, as before) when the scene is degenerate, when big spheres would
-// be listed nearly everywhere, or when the lists would outgrow their 16-bit indices' worth.
+// be listed nearly everywhere, or when the walk would not pay (below). Scenes of more than 65535 spheres have a grid too: their
+// candidates are tested where they are met (the queue's entries are 16 bits).
 static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::vector<float>& p1) {
   double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, cr2max = 0.0, corner2 = 0.0;
   for (uint32_t i = 0; i < n; ++i) {
@@ -601,7 +602,7 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
   // pad the box by the slack so that every inflated + slackened ball lies inside it
   for (int a = 0; a < 3; ++a) { lo[a] -= 2.0 * slack; hi[a] += 2.0 * slack; ext[a] = hi[a] - lo[a]; cell[a] = ext[a] / dim[a]; }
   const size_t ncells = (size_t)dim[0] * dim[1] * dim[2];
-  std::vector<std::vector<uint16_t>> lists(ncells);
+  std::vector<std::vector<uint32_t>> lists(ncells);
   size_t total = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const double Ri = R[i] + slack;
@@ -620,7 +621,7 @@ static int build_grid(rt_ctx* ctx, const rt_sphere* sp, uint32_t n, const std::v
             const double d = c < b0 ? b0 - c : (c > b1 ? c - b1 : 0.0);
             d2 += d * d;
           }
-          if (d2 <= Ri * Ri) { lists[((size_t)z * dim[1] + y) * dim[0] + x].push_back((uint16_t)i); ++total; }
+          if (d2 <= Ri * Ri) { lists[((size_t)z * dim[1] + y) * dim[0] + x].push_back(i); ++total; }
         }
     if (total > 16u * (size_t)n + 4096u) {  // big spheres listed nearly everywhere: the loop over all spheres is the better trace
       if (std::getenv("RT_GRID_VERBOSE")) std::fprintf(stderr, "rt_set_scene: no grid (%u spheres: more than %zu list entries)\n", n, total);
@@ -725,7 +726,7 @@ int rt_set_scene(rt_ctx* ctx, const rt_sphere* spheres, uint32_t n_spheres, cons
   RT_HIP(hipMemcpy(ctx->sph_col, col.data(), bytes, hipMemcpyHostToDevice));
   (void)hipFree(ctx->grid_cells);
   ctx->grid_cells = nullptr;
-  if (tame && n_spheres > 64u && n_spheres <= 0xffffu) {
+  if (tame && n_spheres > 64u) {
     if (int rc = build_grid(ctx, spheres, n_spheres, p1)) return rc;
   }
   ctx->n_spheres = n_spheres;

@@ -932,8 +932,13 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
             }
             // (both arithmetic modes queue here: an exact test inside this loop would run for the one or two lanes that have a
             // candidate in most trips of the wave)
-            if (pass) { queue = (queue << 16) | (unsigned long long)j; qn++; lastj = j; }
-            if (__ballot(qn == 4u)) drain();
+            if (use_queue) {
+              if (pass) { queue = (queue << 16) | (unsigned long long)j; qn++; lastj = j; }
+              if (__ballot(qn == 4u)) drain();
+            } else if (pass) {  // more than 65535 spheres: their indices do not fit the queue's 16-bit entries
+              lastj = j;
+              test_sphere(j, closest, hit, any_untame);
+            }
             // (Measured and left out, profiles/r3_grid_suspend.log: stopping the loop when fewer than 12 / 20 / 28 / 36 / 44 lanes are
             // still walking - they park their walk in LDS and take it up in the next general trace, beside the fresh rays - is
             // bit-identical and 1.5 / 2 / 4 / 8 / 13 % SLOWER: lane-trips are conserved, and the lanes set free wait for the batch.)
