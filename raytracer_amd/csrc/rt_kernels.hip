@@ -255,6 +255,32 @@ __device__ __forceinline__ uint32_t phase1_one(uint32_t missbits, float cx, floa
   const uint32_t key = CULL ? __builtin_amdgcn_bitop3_b32(as_u32(nhb), as_u32(w), as_u32(test), 0xEA) : as_u32(test);
   return __builtin_amdgcn_alignbit(missbits, key, 31);
 }
+// VGPR FORM (an experiment of round 3, off: -DRT_P1_VGPR=1; MASK shape only). The sphere's constants come from LDS (one ds_read_b128
+// per sphere, every lane the same address) and the eight FMAs are v_fma_f32 on vector registers only - class F, which shares its
+// issue window with another wave's instruction, where the scalar-operand form is class S (profiles/r3_valu_ceiling.txt). The FMAs
+// are written as asm because the compiler turns an accumulating fma into v_fmac_f32, the VOP2 form, which is class S again.
+// Measured (profiles/r3_ab_issue_classes.log, "p1v7"): bit-identical, 70 registers, no scratch - and 2.1 % SLOWER on C3, 2.5 % on C2: a
+// v_fma_f32 with three vector sources in allocator-chosen banks issues at 2.7 cycles, not 2.05, and twenty ds_read_b128 per iteration
+// are not free either. The scalar-operand form stays.
+#ifndef RT_P1_VGPR
+#define RT_P1_VGPR 0
+#endif
+#define RT_VFMA_INIT(d, x, y, c) asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(c))
+#define RT_VFMA_ACC(d, x, y) asm("v_fma_f32 %0, %1, %2, %0" : "+v"(d) : "v"(x), "v"(y))
+template <bool CULL>
+__device__ __forceinline__ uint32_t phase1_one_v(uint32_t missbits, f32x4 s, const p1_ray& q) {
+  float nhb, w, test;
+  RT_VFMA_INIT(nhb, s.z, q.dz_nod.x, q.dz_nod.y);
+  RT_VFMA_ACC(nhb, s.y, q.dx_dy.y);
+  RT_VFMA_ACC(nhb, s.x, q.dx_dy.x);
+  RT_VFMA_INIT(w, s.w, q.na_nA.x, q.na_nA.y);
+  RT_VFMA_ACC(w, s.x, q.Px_Py.x);
+  RT_VFMA_ACC(w, s.y, q.Px_Py.y);
+  RT_VFMA_ACC(w, s.z, q.Pz_0.x);
+  RT_VFMA_INIT(test, nhb, nhb, w);
+  const uint32_t key = CULL ? __builtin_amdgcn_bitop3_b32(as_u32(nhb), as_u32(w), as_u32(test), 0xEA) : as_u32(test);
+  return __builtin_amdgcn_alignbit(missbits, key, 31);
+}
 // spheres base..base+cnt_pad-1 (base, cnt_pad multiples of 4): one s_load_dwordx16 per four spheres
 template <bool CULL, bool SCALAR>
 __device__ __forceinline__ uint32_t phase1_missbits(const_f32x16_ptr sph_p1, uint32_t base, uint32_t cnt_pad, const p1_ray& q) {
@@ -427,6 +453,14 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   const float spp_f = (float)a.spp;
   __shared__ f32x4 tile_lds[128];  // per wave: 64 pixel records {pixel_center, v<<16|u} {pixel_delta, seed x^y}
   __shared__ f32x4 sph_lds[SMALL ? 3u * RT_SMALL_MAX : 1u];  // SMALL: sph_test | sph_shade | sph_col of the whole scene
+  __shared__ f32x4 p1_lds[(RT_P1_VGPR && SMALL && SPLIT) ? 32u : 1u];  // RT_P1_VGPR: {cx, cy, cz, K'} of the (<= 32, padded) spheres of a MASK launch
+  if (RT_P1_VGPR && SMALL && SPLIT) {
+    const uint32_t np = (n_spheres + 3u) & ~3u;
+    if (threadIdx.x < np && np <= 32u) {
+      const float* pp = a.sph_p1 + (threadIdx.x >> 1) * 8u + (threadIdx.x & 1u);
+      p1_lds[threadIdx.x] = f32x4{pp[0], pp[2], pp[4], pp[6]};
+    }
+  }
   if (SMALL) {
     for (uint32_t i = threadIdx.x; i < n_spheres; i += 64u) {
       sph_lds[i] = a.sph_test[i];
@@ -1388,7 +1422,16 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
         const float a_fast = ray_prelude(std::integral_constant<bool, true>{}, p1q);
         RT_PROF_END(1);
         RT_PROF_BEGIN(2);
+#if RT_P1_VGPR
+        uint32_t missbits = 0xffffffffu;
+        for (uint32_t i = 0; i < n_pad32; i += 2u) {
+          const f32x4 s0 = p1_lds[i], s1 = p1_lds[i + 1u];
+          missbits = phase1_one_v<CULL>(missbits, s0, p1q);
+          missbits = phase1_one_v<CULL>(missbits, s1, p1q);
+        }
+#else
         const uint32_t missbits = phase1_missbits<CULL, P1S>(sph_p1, 0u, n_pad32, p1q);
+#endif
         cand = (~missbits | (tame ? 0u : 0xffffffffu)) & valid32 & ~(own_sphere_drop(RT_RCP_AT_WALK ? a_fast : a_lit) ? 1u << (n_pad32 - 1u - own) : 0u);
         w_closest = RT_RAY_TMAX; w_hit = 0xffffffffu;  // (own is dead from here on: w_hit shares its register)
         state = ST_TEST;
