@@ -110,6 +110,11 @@ def main():
         on = render(W, H, flags, spheres, mats, cam, 2, {"RT_GRID": "2"})  # 2: the grid trace also below the scene size from which it pays
         off = render(W, H, flags, spheres, mats, cam, 2, {"RT_SPLIT": "0", "RT_SKY_TILES": "0", "RT_GRID": "0"})
         same = np.array_equal(on[0], off[0]) and np.array_equal(on[1], off[1])
+        if not same and math == R.RT_MATH_FAST and np.array_equal(on[1], off[1]):
+            # fast arithmetic may turn a degenerate sphere (radius 0: 1 / r = inf) into NaN colours, and which NaN comes out of an operation
+            # (sign, payload) depends on the operand order the compiler chose in each loop shape: NaN in both images counts as the same
+            fa, fb = on[0].view(np.float32), off[0].view(np.float32)
+            same = bool(np.all((on[0] == off[0]) | (np.isnan(fa) & np.isnan(fb))))
         k = by_kind.setdefault(kind, [0, 0, 0, 0])
         k[0] += 1; k[1] += 0 if same else 1; k[2] += on[2][0]; k[3] += on[2][1]
         if not same:
