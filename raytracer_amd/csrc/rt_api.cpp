@@ -219,7 +219,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   a.cw0 = frame_cw(first_frame);
   a.frame_table = time_table_dev;
   a.inv_spp = (a.spp & (a.spp - 1u)) == 0u ? 1.0f / (float)a.spp : 0.0f;
-  a.batch_lanes = ctx->batch_lanes > 0 ? (uint32_t)ctx->batch_lanes : 3u;  // profiles/r1b_sweep_batch_lanes.log
+  a.batch_lanes = ctx->batch_lanes > 0 ? (uint32_t)ctx->batch_lanes : 3u;  // profiles/r1b_sweep_batch_lanes.log (short units: below)
   a.n_spheres = ctx->n_spheres;
   a.flags = ctx->flags;
   a.p1_tame = ctx->p1_tame ? 1u : 0u;
@@ -292,6 +292,9 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
       a.n_units = my_tiles * a.n_groups;
     }
   }
+  // Short units (a staged launch whose lane finishes a unit within 32 samples: C2's 16 spp x 2 frames) bring a lane to the service section
+  // often: serving six parked lanes at a time instead of three is worth 1.5 % there (profiles/r3_c2_batch_lanes.log); at 64 spp it costs 1 %.
+  if (ctx->batch_lanes <= 0 && a.staging && a.n_spheres <= 64u && a.spp >= 8u && a.spp * a.frame_group <= 32u) a.batch_lanes = 6u;
   // Launch width: 6 waves per SIMD are resident (<= 80 VGPRs); the SMALL variants fit 7 (<= 72 VGPRs), which pays
   // when there are enough units of work to keep 28 waves per CU busy to the end (C3 -1.5 %, batched C2 -4 %; one C2
   // pass with 4.5 tiles per wave: +4 %, so not there)
