@@ -170,9 +170,9 @@ void covered(const rt_ctx* c, uint32_t* cov_w, uint32_t* cov_h) {
 constexpr uint32_t RT_ORDER_REFRESH = 32;  // launches between two measurements of the per-tile cost
 constexpr uint64_t RT_STAGE_BELOW = 32;    // batches are staged per frame when a rank has fewer tiles per wave than this
 constexpr uint32_t RT_STAGE_MIN_SPP = 4;   // below that a (tile, frame) unit is too little work for its hand-out (C1: 1 spp got slower) - unless frames are grouped:
-constexpr uint64_t RT_STAGE_LOW_SPP_BELOW = 2;  // ... a rank with fewer tiles per wave than this (a small image: waves wait more than they issue) stages at 1-3 spp too, in
-                                                // units of (tile, 8 / spp frames): C1 1.70 -> 0.68 ms per 64-frame render (tools/c1_probe.py, profiles/r3_c1_groups.log); not at
-                                                // 1080p and above, where 16 B per sample through the staging buffer would be HBM traffic of the order of the kernel's time
+constexpr uint64_t RT_STAGE_LOW_SPP_BELOW = 2;  // ... a rank with fewer than 2 spp + 2 tiles per wave (a small image: waves wait more than they issue) stages at 1-3 spp too,
+                                                // in units of (tile, <= 16 / spp frames): C1 1.70 -> 0.68 ms per 64-frame render (tools/c1_probe.py, profiles/r3_c1_groups.log); 720p at
+                                                // 1 spp +9 %, 1080p at 2 spp +9 %; not 1080p at 1 spp (-5 %: 16 B per sample through the staging buffer and the combine kernel)
 constexpr size_t RT_STAGE_MAX_BYTES = (size_t)4 << 30;  // largest staging buffer a context allocates
 constexpr uint32_t RT_FRAME_GROUP_MAX = 2u;     // staged launches: frames per unit of work (env RT_FRAME_GROUP overrides; 1 = a unit per frame). C2: 1 / 2 / 4 = 56.4 / 58.1 / 57.8 Gsamples/s, C4 (dear pixels: tails): 5.23 / 5.22 / 4.85 (profiles/r3_sweep_groups.log)
 constexpr uint64_t RT_GROUP_MIN_UNITS = 16u;    // ... while every resident wave keeps at least this many units
@@ -268,7 +268,7 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // hand-out and 1/g tile fetch per g frame ends). g grows while a lane's share of a unit stays at or below RT_GROUP_MAX_SAMPLES
   // samples (at 64 spp a pixel hand-out is 1/64 of the work already and a longer unit only lengthens the launch's tail) and every
   // resident wave keeps enough units: RT_GROUP_MIN_UNITS of them - the staging rule exists because few units per wave mean long
-  // tails - or 3 while a unit is at most 8 samples per lane (short units end evenly). Up to 2 frames, or 16 samples per lane at 1-4 spp.
+  // tails - or 3 while a unit is at most 16 samples per lane (short units end evenly). Up to 2 frames, or 16 samples per lane at 1-4 spp.
   uint32_t g = 1u;
   {
     const bool forced = ctx->frame_group > 0;  // env RT_FRAME_GROUP: that group size (rounded down to a power of two), whatever the launch shape
@@ -276,12 +276,12 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     while (g * 2u <= g_max && g * 2u <= n_frames) {
       const uint64_t units2 = (uint64_t)my_tiles * ((n_frames + 2u * g - 1u) / (2u * g));
       const uint32_t samples2 = a.spp * g * 2u;
-      if (!forced && !(samples2 <= RT_GROUP_MAX_SAMPLES && units2 >= (samples2 <= 8u ? 3u : RT_GROUP_MIN_UNITS) * resident)) break;
+      if (!forced && !(samples2 <= RT_GROUP_MAX_SAMPLES && units2 >= (samples2 <= 16u ? 3u : RT_GROUP_MIN_UNITS) * resident)) break;
       g *= 2u;
     }
   }
   const uint32_t min_spp = ctx->stage_min_spp > 0 ? (uint32_t)ctx->stage_min_spp : RT_STAGE_MIN_SPP;
-  const bool enough_per_unit = a.spp >= min_spp || ((uint64_t)my_tiles < RT_STAGE_LOW_SPP_BELOW * resident && a.spp * g >= min_spp);
+  const bool enough_per_unit = a.spp >= min_spp || ((uint64_t)my_tiles < (RT_STAGE_LOW_SPP_BELOW * a.spp + 2u) * resident && a.spp * g >= min_spp);
   if (!scratch && ctx->use_staging && n_frames > 1 && time_table_dev && enough_per_unit && (uint64_t)my_tiles < RT_STAGE_BELOW * resident &&
       stage_bytes <= stage_limit(ctx) && (uint64_t)my_tiles * n_frames < 0xffffffffull / 64u) {
     if (ctx->staging_bytes < stage_bytes) {

@@ -6,7 +6,7 @@ import raytracer_amd as R
 from raytracer_amd import configs, host
 
 cfg = configs.get("C1")
-W, H, spp, frames = cfg["width"], cfg["height"], cfg["spp"], cfg["frames"]
+W, H, spp, frames = int(os.environ.get("PROBE_W", cfg["width"])), int(os.environ.get("PROBE_H", cfg["height"])), int(os.environ.get("PROBE_SPP", cfg["spp"])), cfg["frames"]
 tb = host.time_table(frames)
 rt = R.Raytracer(W, H, cfg["flags"]); rt.set_scene(cfg["spheres"], cfg["materials"])
 cam = host.camera_raw(W, H, spp=spp, frames=frames)
@@ -25,11 +25,11 @@ rt = R.Raytracer(W, H, cfg["flags"]); rt.set_scene(cfg["spheres"], cfg["material
 rt.set_camera(cam); rt.render_frames(tb); rt.sync()
 rt.enable_timing(True); rt.timing_reset()
 t0 = time.perf_counter()
-for rep in range(200):
+for rep in range(int(os.environ.get('PROBE_REPS', '200'))):
     cam["current_frame"] = 0; rt.set_camera(cam)
     rt.render_frames(tb)
 rt.sync()
 dt = time.perf_counter() - t0
 ms, n = rt.timing()
-print(f"200 renders back to back: {1e3 * dt / 200:.3f} ms per render (wall), path kernel {ms / max(n, 1):.3f} ms per launch over {n} launches", flush=True)
+print(f"{W}x{H} {spp} spp x {frames} frames, renders back to back: {1e3 * dt / int(os.environ.get('PROBE_REPS', '200')):.3f} ms per render (wall), path kernel {ms / max(n, 1):.3f} ms per launch over {n} launches", flush=True)
 rt.close()
