@@ -2,7 +2,7 @@
 # rocprofv3 passes over the bench command. Usage: tools/prof.sh <tag> [bench args...]
 set -o pipefail
 tag=$1; shift
-out=gpurun_out/prof_$tag
+out=gpurun_out/prof_$tag; rm -rf $out  # (a directory left by an earlier run would be mixed into the summary)
 mkdir -p $out
 export TMPDIR=/tmp
 # 20 + 20 passes: the library runs them as two 20-pass launches (it batches up to 64 recorded passes, 32 at 4K), the
