@@ -135,6 +135,7 @@ struct rt_ctx {
   size_t staging_bytes = 0;
   size_t stage_cap = 0;       // largest staging buffer this context allocates (stage_limit(); 0 = not asked yet)
   int use_staging = 1;        // env RT_STAGED_FRAMES=0 keeps batched launches pixel-sequential
+  int queue_chunk = 0;        // env RT_QUEUE_CHUNK (experiments): units a wave takes per atomic on the queue head (0 = the rule in launch())
   int stage_min_spp = 0;      // env RT_STAGE_MIN_SPP (experiments): samples per pixel from which batches may be staged (0 = the rule below)
   int frame_group = 0;        // env RT_FRAME_GROUP: largest frame group of a staged launch (0 = RT_FRAME_GROUP_MAX)
   // deferred passes: rt_compute records (frame, time bits); the passes run as ONE batched launch when `defer_max` of
@@ -307,6 +308,14 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // Short units (a staged launch whose lane finishes a unit within 32 samples: C2's 16 spp x 2 frames) bring a lane to the service section
   // often: serving six parked lanes at a time instead of three is worth 1.5 % there (profiles/r3_c2_batch_lanes.log); at 64 spp it costs 1 %.
   if (ctx->batch_lanes <= 0 && a.staging && a.n_spheres <= 64u && a.spp >= 8u && a.spp * a.frame_group <= 32u) a.batch_lanes = 6u;
+  // Units per atomic on the queue head: 1, unless the units are many and short (at most 4 samples per lane and unit, at least 16 units per
+  // resident wave): then a wave takes up to 16 at a time, a sixth of its share at most. The queue head serves about 86 M atomics per second:
+  // an 8K pass at 1 spp - 518 400 units of one sample per lane - took 6.0 ms that way and takes 0.95 (profiles/r3_queue_chunk.log; env
+  // RT_QUEUE_CHUNK forces a size). Longer units keep 1: chunks of them only lengthen the launch's tail (C3, one pass per launch: 2 -> +5 %).
+  a.queue_chunk = 1u;
+  const uint64_t unit_samples = (uint64_t)a.spp * (a.staging ? a.frame_group : n_frames);
+  if (ctx->queue_chunk > 0) a.queue_chunk = (uint32_t)ctx->queue_chunk;
+  else if (unit_samples <= 4u && (uint64_t)a.n_units >= 16u * resident) a.queue_chunk = (uint32_t)std::min<uint64_t>(16u, a.n_units / (6u * resident));
   // Launch width: 6 waves per SIMD are resident (<= 80 VGPRs); the SMALL variants fit 7 (<= 72 VGPRs), which pays
   // when there are enough units of work to keep 28 waves per CU busy to the end (C3 -1.5 %, batched C2 -4 %; one C2
   // pass with 4.5 tiles per wave: +4 %, so not there)
@@ -516,6 +525,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e5 = std::getenv("RT_STAGED_FRAMES")) c->use_staging = std::atoi(e5);
   if (const char* e6 = std::getenv("RT_FRAME_GROUP")) c->frame_group = std::atoi(e6);
   if (const char* e6 = std::getenv("RT_STAGE_MIN_SPP")) c->stage_min_spp = std::atoi(e6);
+  if (const char* e6 = std::getenv("RT_QUEUE_CHUNK")) c->queue_chunk = std::atoi(e6);
   if (const char* e6 = std::getenv("RT_SKY_TILES")) c->use_sky = std::atoi(e6);
   if (const char* e7 = std::getenv("RT_DEFER_FRAMES")) c->defer_max = std::atoi(e7);
   if (const char* e8 = std::getenv("RT_SPLIT")) c->use_split = std::atoi(e8);
