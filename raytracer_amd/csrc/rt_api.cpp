@@ -135,6 +135,7 @@ struct rt_ctx {
   size_t staging_bytes = 0;
   size_t stage_cap = 0;       // largest staging buffer this context allocates (stage_limit(); 0 = not asked yet)
   int use_staging = 1;        // env RT_STAGED_FRAMES=0 keeps batched launches pixel-sequential
+  int queue_static = -1;      // env RT_QUEUE_STATIC (experiments)
   int queue_chunk = 0;        // env RT_QUEUE_CHUNK (experiments): units a wave takes per atomic on the queue head (0 = the rule in launch())
   int stage_min_spp = 0;      // env RT_STAGE_MIN_SPP (experiments): samples per pixel from which batches may be staged (0 = the rule below)
   int frame_group = 0;        // env RT_FRAME_GROUP: largest frame group of a staged launch (0 = RT_FRAME_GROUP_MAX)
@@ -308,14 +309,29 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
   // Short units (a staged launch whose lane finishes a unit within 32 samples: C2's 16 spp x 2 frames) bring a lane to the service section
   // often: serving six parked lanes at a time instead of three is worth 1.5 % there (profiles/r3_c2_batch_lanes.log); at 64 spp it costs 1 %.
   if (ctx->batch_lanes <= 0 && a.staging && a.n_spheres <= 64u && a.spp >= 8u && a.spp * a.frame_group <= 32u) a.batch_lanes = 6u;
-  // Units per atomic on the queue head: 1, unless the units are many and short (at most 4 samples per lane and unit, at least 16 units per
-  // resident wave): then a wave takes up to 16 at a time, a sixth of its share at most. The queue head serves about 86 M atomics per second:
-  // an 8K pass at 1 spp - 518 400 units of one sample per lane - took 6.0 ms that way and takes 0.95 (profiles/r3_queue_chunk.log; env
-  // RT_QUEUE_CHUNK forces a size). Longer units keep 1: chunks of them only lengthen the launch's tail (C3, one pass per launch: 2 -> +5 %).
+  // HAND-OUT OF UNITS. The queue head serves about 86 M atomics per second - nothing to a launch of long units, the bound of a launch of
+  // short ones: one 1080p pass at 1 spp (32 400 units of one sample per lane; what a host that presents every frame launches) took
+  // 0.46 ms for 0.09 ms of work, one 8K pass 6.0 ms for 0.9 (profiles/r3_per_pass_matrix.md, r3_queue_chunk.log). By the samples s a lane
+  // spends on a unit and the units u per resident wave:
+  //   s <= 4: a wave takes c = min(64, u / 4) units per atomic when that is worth 16 samples per lane (8K at 1 spp, 4K at 4 spp); otherwise
+  //           NO QUEUE (queue_chunk 0): wave w takes units w, w + waves, ... of the cost-ordered list - what dynamic hand-out could
+  //           balance there is less than the atomics cost (640x360 ... 4K at 1 spp: 2.4 - 5.3 x faster, 1080p at 4 spp 2.1 x)
+  //   s <= 8, u < 8 (C1's staged (tile, 8 frames) units: +20 %) and s <= 16, u < 4 (640x360 / 720p at 16 spp: +13 % / +4 %): no queue either
+  //   longer or more units: one unit per atomic - chunks or strides of them only lengthen the launch's tail (1080p at 16 spp: no queue
+  //           -9 %, 4K at 64 spp -28 %; C3, one pass per launch: 2 units per atomic -5 %)
+  // Small scenes only: a sample of the 1024-sphere scene costs five times as much, its tiles differ more, and the queue is worth its atomics
+  // (C4, one pass per launch: no queue -7 %). env RT_QUEUE_STATIC=n: no queue for units of at most n samples (0: never); RT_QUEUE_CHUNK=n: n units per atomic.
   a.queue_chunk = 1u;
-  const uint64_t unit_samples = (uint64_t)a.spp * (a.staging ? a.frame_group : n_frames);
-  if (ctx->queue_chunk > 0) a.queue_chunk = (uint32_t)ctx->queue_chunk;
-  else if (unit_samples <= 4u && (uint64_t)a.n_units >= 16u * resident) a.queue_chunk = (uint32_t)std::min<uint64_t>(16u, a.n_units / (6u * resident));
+  {
+    const uint64_t s = (uint64_t)a.spp * (a.staging ? a.frame_group : n_frames), u = (uint64_t)a.n_units / resident;
+    const uint64_t c = std::min<uint64_t>(64u, std::max<uint64_t>(1u, u / 4u));
+    if (ctx->queue_static >= 0) { if (s <= (uint64_t)ctx->queue_static) a.queue_chunk = 0u; }
+    else if (a.n_spheres <= 64u && ((s <= 4u && c * s < 16u) || (s <= 8u && u < 8u) || (s <= 16u && u < 4u))) a.queue_chunk = 0u;
+    if (a.queue_chunk != 0u) {
+      if (ctx->queue_chunk > 0) a.queue_chunk = (uint32_t)ctx->queue_chunk;
+      else if (s <= 4u && a.n_spheres <= 64u) a.queue_chunk = (uint32_t)c;
+    }
+  }
   // Launch width: 6 waves per SIMD are resident (<= 80 VGPRs); the SMALL variants fit 7 (<= 72 VGPRs), which pays
   // when there are enough units of work to keep 28 waves per CU busy to the end (C3 -1.5 %, batched C2 -4 %; one C2
   // pass with 4.5 tiles per wave: +4 %, so not there)
@@ -526,6 +542,7 @@ int rt_create(rt_ctx** out, int device, uint32_t width, uint32_t height, uint32_
   if (const char* e6 = std::getenv("RT_FRAME_GROUP")) c->frame_group = std::atoi(e6);
   if (const char* e6 = std::getenv("RT_STAGE_MIN_SPP")) c->stage_min_spp = std::atoi(e6);
   if (const char* e6 = std::getenv("RT_QUEUE_CHUNK")) c->queue_chunk = std::atoi(e6);
+  if (const char* e6 = std::getenv("RT_QUEUE_STATIC")) c->queue_static = std::atoi(e6);
   if (const char* e6 = std::getenv("RT_SKY_TILES")) c->use_sky = std::atoi(e6);
   if (const char* e7 = std::getenv("RT_DEFER_FRAMES")) c->defer_max = std::atoi(e7);
   if (const char* e8 = std::getenv("RT_SPLIT")) c->use_split = std::atoi(e8);

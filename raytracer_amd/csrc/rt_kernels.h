@@ -23,7 +23,7 @@ struct rt_kargs {
   uint32_t rank, world;     // tile t belongs to this launch iff t % world == rank
   uint32_t my_tiles;        // number of tiles of this rank: tile = j * world + rank, j < my_tiles
   uint32_t n_units;         // queue length: my_tiles, or my_tiles * n_groups in a staged launch
-  uint32_t queue_chunk;     // units a wave takes per atomic on the queue head (1; more when units are many and short: rt_api.cpp)
+  uint32_t queue_chunk;     // units a wave takes per atomic on the queue head (1; more when units are many and short: rt_api.cpp); 0: no queue, wave w takes units w + k * waves
   uint32_t reject_tries;    // rejection-sampling rounds per loop iteration (>= 1)
   uint32_t spp;
   uint32_t first_frame, n_frames;

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
   // slot = (index of the tile in this rank's tile list) * 64 + (pixel within the 8x8 tile)
   uint32_t q_cur = 0, q_end = 0;
   bool more = true;
-  uint32_t q_next = 0, q_chunk_end = 0;  // wave-uniform: the units [q_next, q_chunk_end) this wave has taken from the queue and not handed out yet
+  uint32_t q_next = a.queue_chunk == 0u ? blockIdx.x : 0u, q_chunk_end = 0;  // wave-uniform: the units [q_next, q_chunk_end) this wave has taken from the queue and not handed out yet (queue_chunk 0: q_next strides)
 
   // per-lane state machine:
   //   NEED_PIXEL -[A]-> NEW_RAY -[G]-> READY -[C]-> PATH_DONE (miss / depth) | READY (mirror) | NEED_DIR (diffuse)
@@ -1178,14 +1178,18 @@ __global__ __launch_bounds__(64, (SMALL && !COUNT) ? (SPLIT ? RT_SPLIT_WAVES : 7
           if (more) {
             // one atomic per `queue_chunk` units: a launch of many short units (an 8K pass at 1 spp: 518 400 tiles of one sample per lane)
             // is otherwise bound by the rate of atomics on this one address (profiles/r3_queue_chunk.log)
-            if (q_next == q_chunk_end) {
+            if (ca->queue_chunk == 0u) {
+              // NO QUEUE: wave w takes units w, w + waves, w + 2 waves, ... of the (cost-ordered) list. For short units the queue head's
+              // ~86 M atomics per second are the launch's bound, and what dynamic hand-out could balance is small (rt_api.cpp, launch())
+              q_chunk_end = q_next < ca->n_units ? q_next + 1u : q_next;
+            } else if (q_next == q_chunk_end) {
               uint32_t b = 0;
               if (lane_id() == 0u) b = atomicAdd(ca->queue, ca->queue_chunk);  // all 64 lanes are active here (uniform loop)
               b = __builtin_amdgcn_readfirstlane(b);
               q_next = b;
               q_chunk_end = b < ca->n_units ? (b + ca->queue_chunk < ca->n_units ? b + ca->queue_chunk : ca->n_units) : b;
             }
-            if (q_next < q_chunk_end) base = q_next++;
+            if (q_next < q_chunk_end) { base = q_next; q_next += ca->queue_chunk == 0u ? gridDim.x : 1u; }
             else { more = false; base = 0xffffffffu; }
           }
           if (base == 0xffffffffu) break;

@@ -998,10 +998,10 @@ def test_sky_tiles_are_off_for_a_non_finite_camera(monkeypatch):
 @pytest.mark.parametrize("knob,value", [("RT_REJECT_TRIES", "1"), ("RT_REJECT_TRIES", "5"), ("RT_BATCH_LANES", "1"), ("RT_BATCH_LANES", "9"),
                                         ("RT_WAVES_PER_CU", "3"), ("RT_WAVES_PER_CU", "32"), ("RT_STAGED_FRAMES", "0"),
                                         ("RT_TILE_ORDER", "0"), ("RT_DEFER_FRAMES", "3"), ("RT_SPLIT", "0"), ("RT_SKY_TILES", "0"), ("RT_FRAME_GROUP", "4"),
-                                        ("RT_QUEUE_CHUNK", "5"), ("RT_QUEUE_CHUNK", "1000"), ("RT_STAGE_MIN_SPP", "1")])
+                                        ("RT_QUEUE_CHUNK", "5"), ("RT_QUEUE_CHUNK", "1000"), ("RT_STAGE_MIN_SPP", "1"), ("RT_QUEUE_STATIC", "64"), ("RT_QUEUE_STATIC", "0")])
 def test_launch_knobs_change_no_bit(knob, value, monkeypatch):
     """Launch width, rejection rounds per iteration, parked lanes per service, staging, tile order, the size of a
-    deferred batch and the units a wave takes per atomic on the queue head only move work between lanes and launches: each pixel consumes its own RNG stream in the
+    deferred batch and how units reach the waves (several per atomic on the queue head, or strided without a queue) only move work between lanes and launches: each pixel consumes its own RNG stream in the
     reference's order, so image and RNG states stay the oracle's."""
     R = _rt()
     W, H, spp, frames = 160, 96, 4, 5
