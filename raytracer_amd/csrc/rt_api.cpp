@@ -278,12 +278,13 @@ int launch(rt_ctx* ctx, uint32_t first_frame, uint32_t n_frames, uint32_t time_b
     while (g * 2u <= g_max && g * 2u <= n_frames) {
       const uint64_t units2 = (uint64_t)my_tiles * ((n_frames + 2u * g - 1u) / (2u * g));
       const uint32_t samples2 = a.spp * g * 2u;
-      if (!forced && !(samples2 <= RT_GROUP_MAX_SAMPLES && units2 >= (samples2 <= 16u ? 3u : RT_GROUP_MIN_UNITS) * resident)) break;
+      // (an image of fewer tiles than resident waves - C1 - needs its frames split finely to fill the machine: 16 units per wave there too)
+      if (!forced && !(samples2 <= RT_GROUP_MAX_SAMPLES && units2 >= (samples2 <= 16u && (uint64_t)my_tiles >= resident ? 3u : RT_GROUP_MIN_UNITS) * resident)) break;
       g *= 2u;
     }
   }
   const uint32_t min_spp = ctx->stage_min_spp > 0 ? (uint32_t)ctx->stage_min_spp : RT_STAGE_MIN_SPP;
-  const bool enough_per_unit = a.spp >= min_spp || ((uint64_t)my_tiles < (RT_STAGE_LOW_SPP_BELOW * a.spp + 2u) * resident && a.spp * g >= min_spp);
+  const bool enough_per_unit = a.spp >= min_spp || ((uint64_t)my_tiles < (RT_STAGE_LOW_SPP_BELOW * a.spp + 2u) * resident && a.spp * g >= std::min(min_spp, 2u));
   if (!scratch && ctx->use_staging && n_frames > 1 && time_table_dev && enough_per_unit && (uint64_t)my_tiles < RT_STAGE_BELOW * resident &&
       stage_bytes <= stage_limit(ctx) && (uint64_t)my_tiles * n_frames < 0xffffffffull / 64u) {
     if (ctx->staging_bytes < stage_bytes) {
