@@ -1603,9 +1603,14 @@ __global__ __launch_bounds__(256) void rt_combine_frames_kernel(const rt_kargs a
 //        discriminant is below -2^-12 a S and the literal one (within 54 2^-24 a S of it) is negative; or
 //   (B)  cos(psi - theta) < -2^-8: the sphere lies behind every ray, literal half_b > 0 and c > 0, both roots <= 0 <= tmin.
 //   Rays must be `tame` (no overflow / underflow in the literal code): |d|^2 in [2^-19, 2^19], |o|^2 <= 2^39, tame scene.
+// WAVE = false: one thread per tile (scenes of at most 32 spheres: a mask). WAVE = true: one WAVE per tile, lane l classifies spheres
+// l, l + 64, ... - for 1024 spheres the thread-per-tile form is 2 x 1024 classifications in a row per thread with 500 waves on the
+// whole chip (0.78 ms per camera change at 1080p, more than a pass of that scene takes); same classification, same lists.
+template <bool WAVE>
 __global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, uint32_t* __restrict__ masks, uint16_t* __restrict__ lists) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= a.my_tiles) return;
+  const uint32_t j = WAVE ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = WAVE ? threadIdx.x & 63u : 0u, stride = WAVE ? 64u : 1u;
+  if (j >= a.my_tiles) return;  // (WAVE: the whole wave)
   const uint32_t tile = j * a.world + a.rank;
   const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
   const double c0[3] = {a.p2w[0], a.p2w[1], a.p2w[2]}, c1[3] = {a.p2w[4], a.p2w[5], a.p2w[6]}, c3[3] = {a.p2w[12], a.p2w[13], a.p2w[14]};
@@ -1687,28 +1692,47 @@ __global__ __launch_bounds__(256) void rt_tile_masks_kernel(const rt_kargs a, ui
     // (first up_min, then the candidates) instead of a per-thread array: the kernel keeps no scratch memory.
     double up_min = 1.0e300;
     bool any = false;
-    for (uint32_t i = 0; i < a.n_spheres; ++i) {
+    for (uint32_t i = lane; i < a.n_spheres; i += stride) {
       double low, up;
       if (classify(i, low, up)) continue;
       any = true;
       if (!per_sphere && !list) break;  // only "sky tile or not" is wanted
       up_min = fmin(up_min, up);
     }
+    if (WAVE) {  // the wave's lanes hold the spheres of ONE tile: combine
+      any = __ballot(any) != 0ull;
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) up_min = fmin(up_min, __shfl_xor(up_min, m, 64));
+    }
     if (any && !per_sphere) mask = everything;
     if (any && (per_sphere || list)) {
       uint32_t kept = 0;
-      for (uint32_t i = 0; i < a.n_spheres; ++i) {
-        double low, up;
-        if (classify(i, low, up) || up_min < low) continue;
-        if (per_sphere) mask |= 1u << (cnt_pad - 1u - i);
-        else if (kept < 15u) list[1u + kept] = (uint16_t)i;  // ascending index: the order hit_sphere's tie rule needs
-        ++kept;
+      if (WAVE) {
+        for (uint32_t base = 0; base < a.n_spheres; base += 64u) {  // (uniform trip count: every lane takes part in the ballots)
+          const uint32_t i = base + lane;
+          double low, up;
+          const bool keep = i < a.n_spheres && !(classify(i, low, up) || up_min < low);
+          const unsigned long long m = __ballot(keep);
+          const uint32_t at = kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (keep && at < 15u) list[1u + at] = (uint16_t)i;  // ascending index: chunks in order, lanes in order within a chunk
+          kept += (uint32_t)__popcll(m);
+        }
+      } else {
+        for (uint32_t i = 0; i < a.n_spheres; ++i) {
+          double low, up;
+          if (classify(i, low, up) || up_min < low) continue;
+          if (per_sphere) mask |= 1u << (cnt_pad - 1u - i);
+          else if (kept < 15u) list[1u + kept] = (uint16_t)i;  // ascending index: the order hit_sphere's tie rule needs
+          ++kept;
+        }
       }
       if (!per_sphere) n_list = kept > 15u ? 0xffffu : kept;
     }
   }
-  masks[j] = mask;
-  if (list) list[0] = (uint16_t)n_list;
+  if (lane == 0u) {
+    masks[j] = mask;
+    if (list) list[0] = (uint16_t)n_list;
+  }
 }
 
 // Tile order for the next launch: counting sort of this launch's per-tile cost, dearest first.
@@ -1819,7 +1843,8 @@ hipError_t rt_launch_combine_frames(const rt_kargs& a, hipStream_t stream) {
 hipError_t rt_launch_tile_masks(const rt_kargs& a, uint32_t* masks, uint16_t* lists, hipStream_t stream) {
   if (a.my_tiles == 0) return hipSuccess;
   if (lists && a.n_spheres > 0xfff0u) lists = nullptr;  // list entries are 16 bits
-  hipLaunchKernelGGL(rt_tile_masks_kernel, dim3((a.my_tiles + 255u) / 256u), dim3(256), 0, stream, a, masks, lists);
+  if (a.n_spheres > 64u) hipLaunchKernelGGL(rt_tile_masks_kernel<true>, dim3((a.my_tiles + 3u) / 4u), dim3(256), 0, stream, a, masks, lists);  // a wave per tile
+  else hipLaunchKernelGGL(rt_tile_masks_kernel<false>, dim3((a.my_tiles + 255u) / 256u), dim3(256), 0, stream, a, masks, lists);
   return hipGetLastError();
 }
 
